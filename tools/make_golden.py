@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by RUNNING THE REFERENCE in the build container.
+
+Usage (build container only; /root/reference does not exist on the GPU box):
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+
+What it does
+  * imports the reference's model modules from /root/reference WITHOUT executing
+    models/__init__.py (that file imports torchvision eagerly) by registering an
+    empty package object whose __path__ points at /root/reference/models;
+  * installs an in-memory torchvision shim (our own pure-torch code) for the three symbols the
+    hot path needs: ops.boxes.batched_nms, transforms.functional.to_tensor and
+    models.utils.load_state_dict_from_url (never called);
+  * loads this repo's deterministic generator weights into the reference modules and saves
+    seeded inputs + reference outputs as small .npz fixtures;
+  * runs the reference MTCNN (real vendored weights) on the reference's own pictures, one
+    image per call (NumPy >= 1.24 ragged-array defect);
+  * asks the container's scikit-image 0.18.3 (/opt/conda python3.9) for
+    SimilarityTransform.estimate on seeded landmark sets.
+
+Only DATA is written to the repo: arrays, and copies of the reference's picture files used as
+detector inputs.  No reference source text is stored.
+"""
+import importlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+from vn_celeb_face_recognition_amd.weights import generate_state_dict  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- shim
+def _nms(boxes, scores, thr):
+    order = torch.sort(scores, descending=True, stable=True)[1]
+    x1, y1, x2, y2 = boxes.unbind(1)
+    areas = (x2 - x1) * (y2 - y1)
+    n = boxes.shape[0]
+    sup = torch.zeros(n, dtype=torch.bool)
+    keep = []
+    for _i in range(n):
+        i = int(order[_i])
+        if sup[i]:
+            continue
+        keep.append(i)
+        rest = order[_i + 1:]
+        xx1 = torch.maximum(x1[i], x1[rest]); yy1 = torch.maximum(y1[i], y1[rest])
+        xx2 = torch.minimum(x2[i], x2[rest]); yy2 = torch.minimum(y2[i], y2[rest])
+        w = (xx2 - xx1).clamp(min=0); h = (yy2 - yy1).clamp(min=0)
+        inter = w * h
+        ovr = inter / (areas[i] + areas[rest] - inter)
+        sup[rest[ovr > thr]] = True
+    return torch.as_tensor(keep, dtype=torch.int64)
+
+
+def _batched_nms(boxes, scores, idxs, iou_threshold):
+    # torchvision's coordinate-offset formulation (_batched_nms_coordinate_trick)
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64)
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    return _nms(boxes + offsets[:, None], scores, iou_threshold)
+
+
+def install_shim():
+    tv = types.ModuleType("torchvision")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    tv.transforms.functional = types.ModuleType("torchvision.transforms.functional")
+    tv.transforms.functional.to_tensor = lambda a: torch.from_numpy(np.ascontiguousarray(np.transpose(a, (2, 0, 1))))
+    tv.ops = types.ModuleType("torchvision.ops")
+    tv.ops.boxes = types.ModuleType("torchvision.ops.boxes")
+    tv.ops.boxes.batched_nms = _batched_nms
+    tv.models = types.ModuleType("torchvision.models")
+    tv.models.utils = types.ModuleType("torchvision.models.utils")
+    tv.models.utils.load_state_dict_from_url = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("offline"))
+    for name, mod in [("torchvision", tv), ("torchvision.transforms", tv.transforms),
+                      ("torchvision.transforms.functional", tv.transforms.functional),
+                      ("torchvision.ops", tv.ops), ("torchvision.ops.boxes", tv.ops.boxes),
+                      ("torchvision.models", tv.models), ("torchvision.models.utils", tv.models.utils)]:
+        sys.modules[name] = mod
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [os.path.join(REF, "models")]
+    sys.modules["models"] = pkg
+
+
+def ref(name):
+    return importlib.import_module("models." + name)
+
+
+# ----------------------------------------------------------------------------- fixtures
+def seeded_normal(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float32)
+
+
+def golden_irv1():
+    m = ref("inception_resnet_v1").InceptionResnetV1(pretrained=None).eval()
+    sd = generate_state_dict("irv1", seed=0, as_torch=True)
+    missing = m.load_state_dict(sd, strict=True)
+    x = seeded_normal((6, 3, 160, 160), 1234)
+    # two real face crops resized by plain slicing (no resampling library involved)
+    from PIL import Image
+    files = sorted(os.listdir(os.path.join(REF, "data")))[:2]
+    for k, f in enumerate(files):
+        a = np.asarray(Image.open(os.path.join(REF, "data", f)).convert("RGB"))[10:170, 10:170]
+        x[4 + k] = torch.from_numpy(((np.float32(a) - 127.5) / 128).transpose(2, 0, 1))
+    taps = {}
+    hooks = []
+    for name in ["conv2d_1a", "conv2d_2b", "conv2d_4b", "repeat_1", "mixed_6a", "repeat_2", "mixed_7a",
+                 "repeat_3", "block8", "last_bn"]:
+        hooks.append(getattr(m, name).register_forward_hook(
+            lambda mod, i, o, name=name: taps.__setitem__(name, o.detach())))
+    with torch.no_grad():
+        y = m(x)
+    for h in hooks:
+        h.remove()
+    stats = {k: np.array([v.mean().item(), v.abs().mean().item(), v.std().item(), v.abs().max().item()],
+                         dtype=np.float64) for k, v in taps.items()}
+    np.savez_compressed(os.path.join(OUT, "irv1_seed0.npz"), input_seed=1234, real_crops=np.array(files),
+                        real_inputs=x[4:6].numpy().astype(np.float16),  # exact: k/128 grid fits fp16
+                        embeddings=y.numpy(), last_bn=taps["last_bn"].numpy(),
+                        block8_sample=taps["block8"][:, ::64].numpy(),
+                        conv2d_4b_sample=taps["conv2d_4b"][:2, ::32, ::4, ::4].numpy(),
+                        **{"stat_" + k: v for k, v in stats.items()})
+    print("irv1:", y.shape, "norms", y.norm(dim=1)[:3].tolist(), "missing", missing)
+
+
+def golden_mlp():
+    m = ref("mlp_model").MLPModel(512, 1001).eval()
+    m.load_state_dict(generate_state_dict("mlp", seed=0, as_torch=True))
+    e = torch.nn.functional.normalize(seeded_normal((32, 512), 77), dim=1)
+    with torch.no_grad():
+        lp = m(e)
+    np.savez_compressed(os.path.join(OUT, "mlp_seed0.npz"), input_seed=77, logp=lp.numpy())
+    print("mlp:", lp.shape, "max prob", lp.exp().max(dim=1)[0][:6].tolist())
+
+
+def golden_ir100():
+    mod = ref("iresnet_encoder")
+    m = mod.iresnet100(pretrained=False, freeze_weights=False).eval()
+    m.load_state_dict(generate_state_dict("iresnet100", seed=0, as_torch=True), strict=True)
+    x = seeded_normal((2, 3, 112, 112), 4321)
+    with torch.no_grad():
+        y = m(x)
+    np.savez_compressed(os.path.join(OUT, "ir100_seed0.npz"), input_seed=4321, features=y.numpy())
+    print("ir100:", y.shape, y.abs().mean().item())
+
+
+def golden_mtcnn():
+    from PIL import Image
+    mt = ref("mtcnn")
+    os.makedirs(os.path.join(OUT, "images"), exist_ok=True)
+    pics = [("images/mrDam_HaHo_recog.jpg", 50), ("images/mrDam_HaHo_recog.jpg", 20),
+            ("images/hoai_linh_4_recog.jpg", 50), ("images/dam_vinh_hung_2_recog.jpg", 40),
+            ("images/QuangLe_PhuongMyChi_recog.png", 30)]
+    pics += [("data/" + f, 20) for f in sorted(os.listdir(os.path.join(REF, "data")))[:3]]
+    out = {}
+    meta = []
+    for rel, mfs in pics:
+        src = os.path.join(REF, rel)
+        dst = os.path.join(OUT, "images", os.path.basename(rel))
+        if not os.path.exists(dst):
+            shutil.copyfile(src, dst)
+            os.chmod(dst, 0o644)
+        img = np.asarray(Image.open(src).convert("RGB"))
+        det = mt.MTCNN(image_size=160, keep_all=True, min_face_size=mfs, device="cpu").eval()
+        boxes, probs, points = det.inference(img, landmark=True)
+        key = "%s@%d" % (os.path.basename(rel), mfs)
+        n = len(boxes)
+        out[key + "/boxes"] = np.asarray(boxes, dtype=np.float32).reshape(n, 4)
+        out[key + "/probs"] = np.asarray(probs, dtype=np.float32).reshape(n)
+        out[key + "/points"] = np.asarray(points, dtype=np.float32).reshape(n, 5, 2)
+        meta.append({"file": os.path.basename(rel), "min_face_size": mfs, "n": int(n), "shape": list(img.shape)})
+        print("mtcnn:", key, img.shape, "->", n, "faces", np.asarray(probs)[:4])
+    # one P-Net level map, to pin the pyramid + P-Net numerics (mrDam, scale index 3 @ minsize 50)
+    img = np.asarray(Image.open(os.path.join(REF, "images/mrDam_HaHo_recog.jpg")).convert("RGB"))
+    df = ref("mtcnn_utils.detect_face")
+    det = mt.MTCNN(min_face_size=50, device="cpu").eval()
+    x = torch.from_numpy(img.copy()).permute(2, 0, 1).unsqueeze(0).float()
+    h, w = img.shape[:2]
+    scale = (12.0 / 50) * 0.709 ** 3
+    with torch.no_grad():
+        lvl = df.imresample(x, (int(h * scale + 1), int(w * scale + 1)))
+        reg, prob = det.pnet((lvl - 127.5) * 0.0078125)
+    out["pnet_level/scale"] = np.float64(scale)
+    out["pnet_level/level"] = lvl.numpy()
+    out["pnet_level/reg"] = reg.numpy()
+    out["pnet_level/prob"] = prob.numpy()
+    np.savez_compressed(os.path.join(OUT, "mtcnn_ref.npz"), **out)
+    with open(os.path.join(OUT, "mtcnn_ref.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+def golden_umeyama():
+    rng = np.random.default_rng(5)
+    tmpl = np.array([[54.706573, 73.85186], [105.045425, 73.573425], [80.036, 102.48086],
+                     [59.356144, 131.95071], [101.04271, 131.72014]], dtype=np.float32)
+    lms = []
+    for k in range(24):
+        ang = rng.uniform(-0.6, 0.6)
+        s = rng.uniform(0.4, 3.0)
+        R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        lm = (tmpl @ R.T) * s + rng.uniform(-40, 200, size=2) + rng.normal(0, 2.0, size=(5, 2))
+        if k == 23:
+            lm[:, 0] = -lm[:, 0] + 300  # mirrored face: exercises the det(A) < 0 branch
+        lms.append(lm.astype(np.float32))
+    lms = np.stack(lms)
+    np.save("/tmp/_lms.npy", lms)
+    np.save("/tmp/_tmpl.npy", tmpl)
+    code = ("import numpy as np\nfrom skimage import transform as trans\n"
+            "l=np.load('/tmp/_lms.npy'); t=np.load('/tmp/_tmpl.npy'); out=[]\n"
+            "for lm in l:\n tf=trans.SimilarityTransform(); tf.estimate(lm, t); out.append(tf.params)\n"
+            "np.save('/tmp/_params.npy', np.stack(out))\n")
+    subprocess.run(["/opt/conda/bin/python3.9", "-c", code], check=True)
+    params = np.load("/tmp/_params.npy")
+    np.savez_compressed(os.path.join(OUT, "align_umeyama.npz"), landmarks=lms, template=tmpl,
+                        skimage_0_18_3_params=params)
+    print("umeyama:", params.shape, params[0])
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    install_shim()
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["irv1", "mlp", "ir100", "mtcnn", "umeyama"]
+    for w in which:
+        globals()["golden_" + w]()
