@@ -1,0 +1,140 @@
+/*
+ * vnface.h -- C ABI of libvnface.so: the MI355X (gfx950) detect -> align -> embed -> classify
+ * hot path of votnhan/VN_celeb_face_recognition, written from scratch in HIP.
+ *
+ * Each entry point replaces one reference interface (file:line under /root/reference):
+ *
+ *   vnf_encoder_create / vnf_embed   models/inception_resnet_v1.py:202,272-303
+ *                                    (InceptionResnetV1.__init__ / forward) and
+ *                                    models/iresnet_encoder.py:139-159,194-196 (iresnet100)
+ *   vnf_mlp_create / vnf_classify    models/mlp_model.py:5-15 (MLPModel) +
+ *                                    demo_image.py:113-137 (argmax / exp / threshold part of
+ *                                    identify_person)
+ *   vnf_mtcnn_create / vnf_mtcnn_detect
+ *                                    models/mtcnn.py:200-227,318-361,511-513 (MTCNN.__init__,
+ *                                    detect, inference) and
+ *                                    models/mtcnn_utils/detect_face.py:25-185 (detect_face)
+ *   vnf_align                        demo_image.py:174-199,236-239,283-295 +
+ *                                    align_face.py:51-57 (crop, move landmarks, Umeyama,
+ *                                    cv2.warpAffine) + data_loader/__init__.py:27-34,52-56
+ *                                    (transforms_default, fused)
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative VNF_E_* code and never throws;
+ *     vnf_last_error() returns a thread-local message for the last failure;
+ *   - the caller owns all input/output buffers; the library owns handles, packed weights and
+ *     workspaces (allocated at create time, sized by max_batch; nothing is allocated on the
+ *     launch path);
+ *   - a handle is bound to the device that was current at create time and is NOT thread-safe
+ *     (one host thread per GPU / rank);
+ *   - all work is enqueued on the caller's hipStream_t (passed as void*); calls do not
+ *     synchronise unless stated;
+ *   - weights are handed over as host fp32 arrays keyed by their reference state_dict names
+ *     (the Python side takes them from torch.load(...); a C caller fills the same table).
+ */
+#ifndef VNFACE_H
+#define VNFACE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VNF_OK 0
+#define VNF_E_INVALID (-1)   /* bad argument / shape */
+#define VNF_E_MISSING (-2)   /* a required weight tensor is absent */
+#define VNF_E_HIP (-3)       /* HIP runtime error */
+#define VNF_E_CAPACITY (-4)  /* batch / candidate count exceeds the handle's capacity */
+
+/* element types */
+#define VNF_F32 0
+#define VNF_BF16 1
+#define VNF_F16 2
+#define VNF_I64 3
+#define VNF_U8 4
+
+/* encoder architectures */
+#define VNF_ARCH_IRV1 0   /* InceptionResnetV1, 160x160 input, L2-normalised 512-d output */
+#define VNF_ARCH_IR100 1  /* IResNet-100 (ArcFace), 112x112 input, 512-d BN1d features */
+
+typedef struct vnf_handle_s* vnf_handle;
+
+typedef struct {
+  const char* name;  /* reference state_dict key, e.g. "repeat_1.0.branch0.conv.weight" */
+  const void* data;  /* host pointer, contiguous */
+  int32_t dtype;     /* VNF_F32 (VNF_I64 entries such as num_batches_tracked are ignored) */
+  int32_t ndim;
+  int64_t shape[4];
+} vnf_tensor_desc;
+
+/* library / device ------------------------------------------------------------------------- */
+int vnf_init(int device_ordinal);          /* hipSetDevice + capability check (gfx950) */
+const char* vnf_last_error(void);
+const char* vnf_version(void);
+int vnf_destroy(vnf_handle h);
+
+/* encoders --------------------------------------------------------------------------------- */
+/* compute_dtype: VNF_BF16 | VNF_F16 (MFMA 16x16x32, fp32 accumulate) or VNF_F32 (exact-f32
+ * MFMA 16x16x4, the <=1e-4 parity path). */
+int vnf_encoder_create(int arch, const vnf_tensor_desc* weights, int n_weights, int compute_dtype,
+                       int max_batch, vnf_handle* out);
+/* x: device pointer, (N,3,S,S) NCHW, already normalised, dtype VNF_F32 | VNF_BF16 | VNF_F16.
+ * emb_out: device pointer, (N,512) fp32. */
+int vnf_embed(vnf_handle h, const void* x, int n, int x_dtype, float* emb_out, void* stream);
+/* debugging / staged parity: copy an internal NHWC activation to a host fp32 NCHW array.
+ * Synchronises the stream.  name is a reference module name ("conv2d_4b", "repeat_2", ...). */
+int vnf_encoder_tap(vnf_handle h, const char* name, int n, float* host_out, int64_t capacity,
+                    int64_t shape_out[4]);
+/* FLOPs of one image through the loaded encoder as the kernels execute it (padded K / channels
+ * included) and as the algorithm defines it; used by bench.py for the roofline line. */
+int vnf_encoder_flops(vnf_handle h, double* algorithmic, double* executed);
+
+/* classifier ------------------------------------------------------------------------------- */
+int vnf_mlp_create(const vnf_tensor_desc* weights, int n_weights, int input_dim, int num_classes,
+                   int max_batch, vnf_handle* out);
+/* emb: device (F,input_dim) fp32.  logp_out: device (F,C) fp32 log-probabilities (may be NULL).
+ * argmax_out: device (F,) int32; prob_out: device (F,) fp32 = exp(logp[argmax]) (may be NULL). */
+int vnf_classify(vnf_handle h, const float* emb, int f, float* logp_out, int32_t* argmax_out,
+                 float* prob_out, void* stream);
+
+/* detector --------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t min_face_size;   /* mtcnn.py:201 */
+  float thresholds[3];     /* mtcnn.py:202 */
+  float factor;            /* mtcnn.py:202 */
+  int32_t select_largest;  /* mtcnn.py:203: order boxes by area, descending */
+  int32_t max_batch;       /* frames per call */
+  int32_t max_height, max_width;
+  int32_t max_candidates;  /* capacity of the per-call candidate tables (0 = default) */
+} vnf_mtcnn_cfg;
+
+int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const vnf_tensor_desc* rnet, int n_rnet,
+                     const vnf_tensor_desc* onet, int n_onet, const vnf_mtcnn_cfg* cfg, vnf_handle* out);
+/* frames: device (B,H,W,3) uint8 RGB.  Results stay on the device for vnf_align and are also
+ * copied to the caller's host arrays (this call synchronises the stream once, at the end):
+ *   counts[B]            faces per frame
+ *   boxes[max_out*4]     x1,y1,x2,y2 fp32, frames concatenated in order
+ *   probs[max_out]
+ *   points[max_out*10]   (5,2) landmarks
+ * n_out receives the total number of faces; VNF_E_CAPACITY if it exceeds max_out. */
+int vnf_mtcnn_detect(vnf_handle h, const uint8_t* frames, int b, int height, int width,
+                     int32_t* counts, float* boxes, float* probs, float* points, int max_out,
+                     int32_t* n_out, void* stream);
+
+/* alignment -------------------------------------------------------------------------------- */
+/* For each of n faces: crop rectangle from its box (demo_image.py:179-182), landmarks moved by
+ * the float box corner (236-239), Umeyama similarity landmarks -> template (align_face.py:52-54),
+ * fixed-point bilinear warp into S x S (cv2.warpAffine, borderValue 0, the crop being the
+ * source image), then optionally (x-127.5)/128 to NCHW.
+ *   frames: device (B,H,W,3) u8; frame_idx: device (n,) int32; boxes: device (n,4) fp32;
+ *   points: device (n,10) fp32; template5x2: host 10 floats.
+ *   faces_u8: device (n,S,S,3) u8 or NULL; faces_norm: device (n,3,S,S) of norm_dtype or NULL. */
+int vnf_align(const uint8_t* frames, int b, int height, int width, const int32_t* frame_idx,
+              const float* boxes, const float* points, int n, const float* template5x2, int s,
+              uint8_t* faces_u8, void* faces_norm, int norm_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VNFACE_H */

@@ -116,3 +116,61 @@ def irv1_forward(sd, x, taps=None):
                          _t(sd, "last_bn.weight"), _t(sd, "last_bn.bias"), False, 0.0, BN_EPS)
         tap("last_bn", x)
         return F.normalize(x, p=2, dim=1)
+
+
+def irv1_forward_quantised(sd, x, qdtype):
+    """The same forward with the HIP 16-bit path's quantisation points: BN-folded conv weights and
+    every stored activation rounded to `qdtype` (torch.bfloat16 / torch.float16), accumulation,
+    bias, residual and activation in fp32.  Used only to separate kernel correctness from
+    16-bit precision in the GPU parity tests."""
+    def q(t):
+        return t.to(qdtype).float()
+
+    def fold(p):
+        w = _t(sd, p + ".conv.weight")
+        s = _t(sd, p + ".bn.weight").double() / torch.sqrt(_t(sd, p + ".bn.running_var").double() + BN_EPS)
+        b = _t(sd, p + ".bn.bias").double() - _t(sd, p + ".bn.running_mean").double() * s
+        return q(w * s.float().view(-1, 1, 1, 1)), b.float()
+
+    def bc(p, x, stride=1, padding=0):
+        w, b = fold(p)
+        return q(F.relu(F.conv2d(x, w, b, stride, padding)))
+
+    def res(p, x, cat, scale, relu=True):
+        w = q(_t(sd, p + ".conv2d.weight") * scale)
+        out = F.conv2d(cat, w, _t(sd, p + ".conv2d.bias") * scale) + x
+        return q(F.relu(out) if relu else out)
+
+    with torch.no_grad():
+        x = q(x.float())
+        x = bc("conv2d_1a", x, 2); x = bc("conv2d_2a", x); x = bc("conv2d_2b", x, 1, 1)
+        x = F.max_pool2d(x, 3, 2)
+        x = bc("conv2d_3b", x); x = bc("conv2d_4a", x); x = bc("conv2d_4b", x, 2)
+        for i in range(5):
+            p = "repeat_1.%d" % i
+            x0 = bc(p + ".branch0", x)
+            x1 = bc(p + ".branch1.1", bc(p + ".branch1.0", x), 1, 1)
+            x2 = bc(p + ".branch2.2", bc(p + ".branch2.1", bc(p + ".branch2.0", x), 1, 1), 1, 1)
+            x = res(p, x, torch.cat((x0, x1, x2), 1), 0.17)
+        x0 = bc("mixed_6a.branch0", x, 2)
+        x1 = bc("mixed_6a.branch1.2", bc("mixed_6a.branch1.1", bc("mixed_6a.branch1.0", x), 1, 1), 2)
+        x = torch.cat((x0, x1, F.max_pool2d(x, 3, 2)), 1)
+        for i in range(10):
+            p = "repeat_2.%d" % i
+            x0 = bc(p + ".branch0", x)
+            x1 = bc(p + ".branch1.2", bc(p + ".branch1.1", bc(p + ".branch1.0", x), 1, (0, 3)), 1, (3, 0))
+            x = res(p, x, torch.cat((x0, x1), 1), 0.10)
+        x0 = bc("mixed_7a.branch0.1", bc("mixed_7a.branch0.0", x), 2)
+        x1 = bc("mixed_7a.branch1.1", bc("mixed_7a.branch1.0", x), 2)
+        x2 = bc("mixed_7a.branch2.2", bc("mixed_7a.branch2.1", bc("mixed_7a.branch2.0", x), 1, 1), 2)
+        x = torch.cat((x0, x1, x2, F.max_pool2d(x, 3, 2)), 1)
+        for i in range(6):
+            p = "repeat_3.%d" % i if i < 5 else "block8"
+            x0 = bc(p + ".branch0", x)
+            x1 = bc(p + ".branch1.2", bc(p + ".branch1.1", bc(p + ".branch1.0", x), 1, (0, 1)), 1, (1, 0))
+            x = res(p, x, torch.cat((x0, x1), 1), 0.20 if i < 5 else 1.0, relu=i < 5)
+        x = q(F.adaptive_avg_pool2d(x, 1).view(x.shape[0], -1))
+        s = _t(sd, "last_bn.weight").double() / torch.sqrt(_t(sd, "last_bn.running_var").double() + BN_EPS)
+        b = (_t(sd, "last_bn.bias").double() - _t(sd, "last_bn.running_mean").double() * s).float()
+        x = F.linear(x, q(_t(sd, "last_linear.weight") * s.float().view(-1, 1)), b)
+        return F.normalize(x, p=2, dim=1)

@@ -1,0 +1,98 @@
+"""GPU parity of the HIP encoder path (through the C ABI) against the oracle and the goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, seeded_normal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def irv1_sd():
+    from vn_celeb_face_recognition_amd.weights import generate_state_dict
+    return generate_state_dict("irv1", 0, as_torch=True)
+
+
+def _golden_inputs():
+    g = np.load(os.path.join(GOLDEN, "irv1_seed0.npz"))
+    x = seeded_normal((6, 3, 160, 160), g["input_seed"])
+    x[4:6] = torch.from_numpy(g["real_inputs"].astype(np.float32))
+    return g, x
+
+
+def test_irv1_f32_matches_reference_golden_1e4():
+    """fp32 MFMA path vs embeddings produced by the reference itself: L2 error <= 1e-4 (north_star)."""
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    g, x = _golden_inputs()
+    m = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype="f32", max_batch=8).eval()
+    y = m(x.cuda()).cpu().numpy()
+    err = np.linalg.norm(y - g["embeddings"], axis=1)
+    assert err.max() <= 1e-4, err
+    assert np.allclose(np.linalg.norm(y, axis=1), 1.0, atol=1e-5)
+
+
+def test_irv1_f32_stage_taps_match_oracle(irv1_sd):
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    from oracle import irv1
+    x = seeded_normal((3, 3, 160, 160), 99)
+    taps = {}
+    ref = irv1.irv1_forward(irv1_sd, x, taps=taps).numpy()
+    m = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype="f32", max_batch=4).eval()
+    y = m(x.cuda()).cpu().numpy()
+    for name in ["conv2d_1a", "conv2d_2a", "conv2d_2b", "maxpool_3a", "conv2d_3b", "conv2d_4a", "conv2d_4b",
+                 "repeat_1", "mixed_6a", "repeat_2", "mixed_7a", "repeat_3", "block8"]:
+        got = m.tap(name, 3)
+        want = taps[name].numpy()
+        assert got.shape == want.shape, name
+        # fp32 with a different summation order: 1e-4 absolute on O(1..10) activations
+        assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), name
+    assert np.linalg.norm(y - ref, axis=1).max() <= 1e-4
+
+
+@pytest.mark.parametrize("dt,tol_emul,tol_f32", [("bf16", 2e-2, 6e-2), ("f16", 4e-3, 8e-3)])
+def test_irv1_16bit_paths(irv1_sd, dt, tol_emul, tol_f32):
+    """16-bit storage / fp32-accumulate MFMA path.  Two checks:
+    (a) against the fp32 oracle: the bench dtype's accuracy, stated (L2 of unit embeddings);
+    (b) against the oracle run with the SAME quantisation points (weights and every stored
+        activation rounded to the 16-bit type): isolates kernel correctness from precision."""
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    from oracle import irv1
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    x = seeded_normal((4, 3, 160, 160), 7)
+    ref32 = irv1.irv1_forward(irv1_sd, x).numpy()
+    refq = irv1.irv1_forward_quantised(irv1_sd, x, tdt).numpy()
+    m = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=4).eval()
+    y = m(x.cuda()).cpu().numpy()
+    e_emul = np.linalg.norm(y - refq, axis=1).max()
+    e_f32 = np.linalg.norm(y - ref32, axis=1).max()
+    print("irv1 %s: L2 vs quantised oracle %.3e, vs fp32 oracle %.3e" % (dt, e_emul, e_f32))
+    assert e_emul <= tol_emul
+    assert e_f32 <= tol_f32
+    cos = (y * ref32).sum(axis=1)
+    assert cos.min() >= 0.998
+
+
+def test_irv1_batch_independence_and_ragged_batches():
+    """eval-mode BN => per-image results do not depend on batch composition; odd batch sizes,
+    batches larger than max_batch and the empty batch all work."""
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    m = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype="bf16", max_batch=5).eval()
+    x = seeded_normal((13, 3, 160, 160), 3).cuda()
+    y_all = m(x)
+    y_one = torch.cat([m(x[i:i + 1]) for i in range(13)])
+    assert torch.equal(y_all, y_one)
+    assert m(x[:0]).shape == (0, 512)
+    yb = m(x.to(torch.bfloat16))
+    assert yb.shape == (13, 512)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 3, 112, 112, device="cuda"))
+
+
+def test_encoder_refuses_cpu():
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    m = InceptionResnetV1(pretrained=None).eval()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 160, 160))

@@ -1,0 +1,182 @@
+// HBM-bound helper kernels around the convolution core: layout packing, pooling, L2 norm.
+// All are coalesced streaming kernels (16-byte accesses along the NHWC channel axis).
+#include "kernels.h"
+
+namespace vnf {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
+
+// ---------------------------------------------------------------- NCHW (n,3,S,S) -> NHWC8
+template <typename TI, typename TO>
+__global__ void pack_input_kernel(const TI* __restrict__ x, TO* __restrict__ y, int n, int hw) {
+  const size_t total = (size_t)n * hw;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t img = i / hw, p = i - img * hw;
+    const TI* src = x + img * 3 * (size_t)hw + p;
+    TO o[8];
+    o[0] = (TO)to_f(src[0]);
+    o[1] = (TO)to_f(src[hw]);
+    o[2] = (TO)to_f(src[2 * (size_t)hw]);
+#pragma unroll
+    for (int c = 3; c < 8; ++c) o[c] = (TO)0.f;
+    TO* dst = y + i * 8;
+    if constexpr (sizeof(TO) == 2) {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
+    } else {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
+      *reinterpret_cast<uint4*>(dst + 4) = *reinterpret_cast<const uint4*>(o + 4);
+    }
+  }
+}
+
+template <typename TI>
+static hipError_t pack_dispatch_out(const void* x, void* out, int dtype, int n, int hw, hipStream_t s) {
+  const size_t total = (size_t)n * hw;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (blocks == 0) return hipSuccess;
+  switch (dtype) {
+    case BF16: hipLaunchKernelGGL((pack_input_kernel<TI, __bf16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (__bf16*)out, n, hw); break;
+    case F16: hipLaunchKernelGGL((pack_input_kernel<TI, _Float16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (_Float16*)out, n, hw); break;
+    case F32: hipLaunchKernelGGL((pack_input_kernel<TI, float>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (float*)out, n, hw); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_input(const void* x, int x_dtype, void* out, int dtype, int n, int hw, hipStream_t s) {
+  switch (x_dtype) {
+    case F32: return pack_dispatch_out<float>(x, out, dtype, n, hw, s);
+    case BF16: return pack_dispatch_out<__bf16>(x, out, dtype, n, hw, s);
+    case F16: return pack_dispatch_out<_Float16>(x, out, dtype, n, hw, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------- max pool 3x3 stride 2
+template <typename T>
+__global__ void maxpool3s2_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int n, int H, int W,
+                                  int C) {
+  constexpr int CH = 16 / (int)sizeof(T);
+  const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1, cc = C / CH;
+  const size_t total = (size_t)n * Ho * Wo * cc;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cc) * CH;
+    const size_t p = i / cc;
+    const int wo = (int)(p % Wo);
+    const size_t q = p / Wo;
+    const int ho = (int)(q % Ho);
+    const size_t img = q / Ho;
+    float m[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) m[e] = -3.4e38f;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const T* src = x + ((img * H + (2 * ho + dh)) * W + (2 * wo + dw)) * (size_t)ldx + c;
+        T v[CH];
+        *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(src);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+      }
+    T o[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) o[e] = (T)m[e];
+    *reinterpret_cast<uint4*>(y + p * (size_t)ldy + c) = *reinterpret_cast<const uint4*>(o);
+  }
+}
+
+hipError_t launch_maxpool3s2(const void* x, int ldx, void* y, int ldy, int dtype, int n, int H, int W, int C,
+                             hipStream_t s) {
+  const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
+  const int ch = 16 / dtype_size(dtype);
+  if (C % ch) return hipErrorInvalidValue;
+  const size_t total = (size_t)n * Ho * Wo * (C / ch);
+  if (total == 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  switch (dtype) {
+    case BF16: hipLaunchKernelGGL(maxpool3s2_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)x, ldx, (__bf16*)y, ldy, n, H, W, C); break;
+    case F16: hipLaunchKernelGGL(maxpool3s2_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)x, ldx, (_Float16*)y, ldy, n, H, W, C); break;
+    case F32: hipLaunchKernelGGL(maxpool3s2_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, n, H, W, C); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- global average pool
+template <typename T>
+__global__ void avgpool_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int n, int HW, int C) {
+  const size_t total = (size_t)n * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t img = i / C;
+    const int c = (int)(i - img * C);
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += (float)x[(img * HW + p) * (size_t)ldx + c];
+    y[i] = (T)(s / (float)HW);
+  }
+}
+
+hipError_t launch_avgpool(const void* x, int ldx, void* y, int dtype, int n, int HW, int C, hipStream_t s) {
+  const size_t total = (size_t)n * C;
+  if (total == 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256);
+  switch (dtype) {
+    case BF16: hipLaunchKernelGGL(avgpool_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)x, ldx, (__bf16*)y, n, HW, C); break;
+    case F16: hipLaunchKernelGGL(avgpool_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)x, ldx, (_Float16*)y, n, HW, C); break;
+    case F32: hipLaunchKernelGGL(avgpool_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, ldx, (float*)y, n, HW, C); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- row-wise L2 normalisation
+// one wave per row: F.normalize(x, p=2, dim=1) = x / max(||x||, 1e-12) (inception_resnet_v1.py:302)
+__global__ void l2norm_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int C) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float* xr = x + (size_t)row * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c] * xr[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float d = fmaxf(sqrtf(s), 1e-12f);
+  for (int c = lane; c < C; c += 64) y[(size_t)row * C + c] = xr[c] / d;
+}
+
+hipError_t launch_l2norm(const float* x, float* y, int n, int C, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(l2norm_kernel, dim3((n + 3) / 4), dim3(256), 0, s, x, y, n, C);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- NHWC slice -> NCHW fp32 (taps)
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, int ldx, float* __restrict__ y, int n, int HW, int C) {
+  const size_t total = (size_t)n * HW * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const size_t q = i / HW;
+    const int c = (int)(q % C);
+    const size_t img = q / C;
+    y[i] = (float)x[(img * HW + p) * (size_t)ldx + c];
+  }
+}
+
+hipError_t launch_nhwc_to_nchw_f32(const void* x, int ldx, int dtype, float* y, int n, int HW, int C, hipStream_t s) {
+  const size_t total = (size_t)n * HW * C;
+  if (total == 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  switch (dtype) {
+    case BF16: hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)x, ldx, y, n, HW, C); break;
+    case F16: hipLaunchKernelGGL(nhwc_to_nchw_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)x, ldx, y, n, HW, C); break;
+    case F32: hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, ldx, y, n, HW, C); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace vnf

@@ -1,0 +1,501 @@
+// Encoder engine: folds BatchNorm into packed MFMA-ready weights, lays activations out as NHWC
+// slices of a small set of device buffers (concat-free inception branches), and replays a
+// static plan of convolution / pooling launches on the caller's stream.
+#include "engine.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace vnf {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+const char* last_error_cstr() { return g_err.c_str(); }
+
+HandleBase::~HandleBase() {
+  for (void* p : allocs) (void)hipFree(p);
+}
+void* HandleBase::dalloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
+    return nullptr;
+  }
+  allocs.push_back(p);
+  return p;
+}
+void* HandleBase::upload(const void* host, size_t bytes) {
+  void* p = dalloc(bytes);
+  if (!p) return nullptr;
+  hipError_t e = hipMemcpy(p, host, bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    set_error(std::string("hipMemcpy H2D: ") + hipGetErrorString(e));
+    return nullptr;
+  }
+  return p;
+}
+
+WeightMap::WeightMap(const vnf_tensor_desc* w, int n) {
+  for (int i = 0; i < n; ++i)
+    if (w[i].name) m[w[i].name] = &w[i];
+}
+const float* WeightMap::get(const std::string& name, int64_t numel) {
+  auto it = m.find(name);
+  if (it == m.end() || it->second->dtype != VNF_F32 || !it->second->data) {
+    if (missing.empty()) missing = name;
+    return nullptr;
+  }
+  int64_t n = 1;
+  for (int i = 0; i < it->second->ndim; ++i) n *= it->second->shape[i];
+  if (n != numel) {
+    if (missing.empty()) missing = name + " (unexpected size)";
+    return nullptr;
+  }
+  return (const float*)it->second->data;
+}
+
+static inline uint16_t f2bf16(float f) {  // round to nearest even, NaN preserved
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+void convert_to(int dtype, const float* src, void* dst, size_t n) {
+  if (dtype == F32) {
+    memcpy(dst, src, n * 4);
+  } else if (dtype == BF16) {
+    uint16_t* d = (uint16_t*)dst;
+    for (size_t i = 0; i < n; ++i) d[i] = f2bf16(src[i]);
+  } else {
+    _Float16* d = (_Float16*)dst;
+    for (size_t i = 0; i < n; ++i) d[i] = (_Float16)src[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+int Encoder::add_buf(int H, int W, int C) {
+  Buf b;
+  b.H = H; b.W = W; b.C = C;
+  bufs.push_back(b);
+  return (int)bufs.size() - 1;
+}
+
+int Encoder::finalize() {
+  const int es = dtype_size(dtype);
+  for (auto& b : bufs) {
+    b.ptr = (char*)dalloc(b.elems_per_image() * es * (size_t)max_batch);
+    if (!b.ptr) return VNF_E_HIP;
+  }
+  emb_raw = (float*)dalloc((size_t)max_batch * 512 * 4);
+  if (!emb_raw) return VNF_E_HIP;
+  macs_alg = macs_exec = 0;
+  for (auto& c : convs) { macs_alg += c.macs_alg; macs_exec += c.macs_exec; }
+  return VNF_OK;
+}
+
+struct Piece {  // output channels contributed by one reference conv / linear
+  const float* w;  // [cout][cin][KH][KW]
+  int cout, cout_pad;
+  std::vector<float> scale, bias;  // per logical output channel
+  std::vector<float> slope;        // optional PReLU slopes
+};
+
+struct SegSpec { int c0, c1, buf, coff; };
+
+struct ConvSpec {
+  std::string name;
+  int x_buf, x_coff = 0, cin, cin_pad;
+  int KH = 1, KW = 1, sh = 1, sw = 1, ph = 0, pw = 0;
+  std::vector<Piece> pieces;
+  std::vector<SegSpec> segs;
+  int res_buf = -1, res_coff = 0;
+  int act = ACT_RELU, out_f32 = 0;
+  // folded pre-conv BatchNorm (IR-100 bn1): x' = x*pre_s[c] + pre_t[c] on valid (unpadded) taps
+  const std::vector<float>* pre_s = nullptr;
+  const std::vector<float>* pre_t = nullptr;
+};
+
+static int add_conv(Encoder& e, const ConvSpec& s) {
+  const int es = dtype_size(e.dtype), ch = 16 / es, bke = 128 / es;
+  const Buf& xb = e.bufs[s.x_buf];
+  ConvLayer L;
+  L.name = s.name;
+  L.x_buf = s.x_buf; L.x_coff = s.x_coff; L.cin = s.cin_pad;
+  L.H = xb.H; L.W = xb.W;
+  L.KH = s.KH; L.KW = s.KW; L.sh = s.sh; L.sw = s.sw; L.ph = s.ph; L.pw = s.pw;
+  L.Ho = (L.H + 2 * s.ph - s.KH) / s.sh + 1;
+  L.Wo = (L.W + 2 * s.pw - s.KW) / s.sw + 1;
+  if (s.cin_pad % ch || s.x_coff % ch || xb.C % ch) return fail(VNF_E_INVALID, s.name + ": channel alignment");
+  L.K = s.KH * s.KW * s.cin_pad;
+  L.Kpad = (L.K + bke - 1) / bke * bke;
+  int cout = 0, cout_logical = 0;
+  for (auto& p : s.pieces) { cout += p.cout_pad; cout_logical += p.cout; }
+  L.cout = cout;
+  L.cout_pad = (cout + 127) / 128 * 128;
+  L.ncls = s.pre_s ? 9 : 1;
+  if (cout % 8) return fail(VNF_E_INVALID, s.name + ": cout % 8");
+
+  std::vector<float> wpk((size_t)L.cout_pad * L.Kpad, 0.f);
+  std::vector<float> bias((size_t)L.ncls * L.cout_pad, 0.f), slope((size_t)L.cout_pad, 0.f);
+  bool has_slope = false;
+  int co0 = 0;
+  for (auto& p : s.pieces) {
+    if (!p.w) return fail(VNF_E_MISSING, s.name + ": weight missing");
+    for (int co = 0; co < p.cout; ++co) {
+      const float sc = p.scale.empty() ? 1.f : p.scale[co];
+      float* dst = &wpk[(size_t)(co0 + co) * L.Kpad];
+      for (int c = 0; c < s.cin; ++c) {
+        const float ps = s.pre_s ? (*s.pre_s)[c] : 1.f;
+        for (int kh = 0; kh < s.KH; ++kh)
+          for (int kw = 0; kw < s.KW; ++kw) {
+            const float wv = p.w[(((size_t)co * s.cin + c) * s.KH + kh) * s.KW + kw];
+            dst[(kh * s.KW + kw) * s.cin_pad + c] = wv * sc * ps;
+          }
+      }
+      const float b = p.bias.empty() ? 0.f : p.bias[co];
+      if (!s.pre_s) {
+        bias[co0 + co] = b;
+      } else {
+        // border classes: the BN shift only reaches the output through taps that land inside
+        // the image; class (r,c) in {first, interior, last}^2 selects the valid tap set.
+        for (int rc = 0; rc < 3; ++rc)
+          for (int cc = 0; cc < 3; ++cc) {
+            double acc = 0;
+            for (int kh = 0; kh < s.KH; ++kh) {
+              if ((rc == 0 && kh < s.ph) || (rc == 2 && kh >= s.KH - s.ph)) continue;
+              for (int kw = 0; kw < s.KW; ++kw) {
+                if ((cc == 0 && kw < s.pw) || (cc == 2 && kw >= s.KW - s.pw)) continue;
+                for (int c = 0; c < s.cin; ++c)
+                  acc += (double)p.w[(((size_t)co * s.cin + c) * s.KH + kh) * s.KW + kw] * (*s.pre_t)[c];
+              }
+            }
+            bias[(size_t)(rc * 3 + cc) * L.cout_pad + co0 + co] = b + (float)(acc * sc);
+          }
+      }
+      if (!p.slope.empty()) { slope[co0 + co] = p.slope[co]; has_slope = true; }
+    }
+    co0 += p.cout_pad;
+  }
+  std::vector<char> wdev((size_t)L.cout_pad * L.Kpad * es);
+  convert_to(e.dtype, wpk.data(), wdev.data(), wpk.size());
+  L.w = e.upload(wdev.data(), wdev.size());
+  L.bias = (float*)e.upload(bias.data(), bias.size() * 4);
+  if (has_slope) L.slope = (float*)e.upload(slope.data(), slope.size() * 4);
+  std::vector<int4> kt(L.Kpad / ch);
+  for (int kc = 0; kc < L.Kpad / ch; ++kc) {
+    const int k = kc * ch;
+    if (k < L.K) {
+      const int tap = k / s.cin_pad, c = k % s.cin_pad, kh = tap / s.KW, kw = tap % s.KW;
+      kt[kc] = int4{(kh * L.W + kw) * xb.C + c, kh, kw, 1};
+    } else {
+      kt[kc] = int4{0, 0, 0, 0};
+    }
+  }
+  L.ktab = (int4*)e.upload(kt.data(), kt.size() * sizeof(int4));
+  if (!L.w || !L.bias || !L.ktab) return VNF_E_HIP;
+
+  L.nseg = (int)s.segs.size();
+  if (L.nseg < 1 || L.nseg > 4) return fail(VNF_E_INVALID, s.name + ": segments");
+  for (int i = 0; i < L.nseg; ++i) {
+    L.seg[i].c0 = s.segs[i].c0; L.seg[i].c1 = s.segs[i].c1;
+    L.seg[i].buf = s.segs[i].buf; L.seg[i].coff = s.segs[i].coff;
+    if (s.segs[i].buf >= 0) {
+      const Buf& ob = e.bufs[s.segs[i].buf];
+      if (ob.H != L.Ho || ob.W != L.Wo || s.segs[i].coff + (s.segs[i].c1 - s.segs[i].c0) > ob.C)
+        return fail(VNF_E_INVALID, s.name + ": output buffer shape");
+    }
+  }
+  L.res_buf = s.res_buf; L.res_coff = s.res_coff;
+  L.act = s.act; L.out_f32 = s.out_f32;
+  L.macs_alg = (double)L.Ho * L.Wo * cout_logical * (double)(s.KH * s.KW * s.cin);
+  const int k32 = (L.K + bke / 2 - 1) / (bke / 2) * (bke / 2);
+  L.macs_exec = (double)L.Ho * L.Wo * cout * (double)k32;
+  e.convs.push_back(L);
+  Op op; op.kind = Op::CONV; op.a = (int)e.convs.size() - 1;
+  e.ops.push_back(op);
+  return VNF_OK;
+}
+
+static bool bn_fold(WeightMap& wm, const std::string& p, int C, float eps, std::vector<float>& s, std::vector<float>& t) {
+  const float* g = wm.get(p + ".weight", C);
+  const float* b = wm.get(p + ".bias", C);
+  const float* m = wm.get(p + ".running_mean", C);
+  const float* v = wm.get(p + ".running_var", C);
+  if (!g || !b || !m || !v) return false;
+  s.resize(C); t.resize(C);
+  for (int i = 0; i < C; ++i) {
+    const double sc = (double)g[i] / std::sqrt((double)v[i] + (double)eps);
+    s[i] = (float)sc;
+    t[i] = (float)((double)b[i] - (double)m[i] * sc);
+  }
+  return true;
+}
+
+// BasicConv2d (inception_resnet_v1.py:12-33): conv(no bias) -> BN(eps 1e-3) -> ReLU
+static bool basic_piece(WeightMap& wm, const std::string& p, int cin, int cout, int kh, int kw, Piece& out, int cout_pad = 0) {
+  out.w = wm.get(p + ".conv.weight", (int64_t)cout * cin * kh * kw);
+  out.cout = cout;
+  out.cout_pad = cout_pad ? cout_pad : cout;
+  return out.w && bn_fold(wm, p + ".bn", cout, 1e-3f, out.scale, out.bias);
+}
+
+static void add_maxpool(Encoder& e, int in_buf, int out_buf, int out_coff) {
+  Op op; op.kind = Op::MAXPOOL; op.a = in_buf; op.b = out_buf; op.c = out_coff;
+  e.ops.push_back(op);
+}
+
+#define TRY(x) do { int _r = (x); if (_r != VNF_OK) return _r; } while (0)
+#define NEED(x) do { if (!(x)) return fail(VNF_E_MISSING, "missing weight: " + wm.missing); } while (0)
+
+int build_irv1(Encoder& e, WeightMap& wm) {
+  e.in_size = 160;
+  const int ch = 16 / dtype_size(e.dtype);
+  (void)ch;
+  const int b_in = e.add_buf(160, 160, 8);
+  const int b_1a = e.add_buf(79, 79, 32), b_2a = e.add_buf(77, 77, 32), b_2b = e.add_buf(77, 77, 64);
+  const int b_3a = e.add_buf(38, 38, 64), b_3b = e.add_buf(38, 38, 96), b_4a = e.add_buf(36, 36, 192);
+  const int x35[3] = {e.add_buf(17, 17, 256), e.add_buf(17, 17, 256), e.add_buf(17, 17, 256)};
+  const int t35a = e.add_buf(17, 17, 64), t35b = e.add_buf(17, 17, 32), cat35 = e.add_buf(17, 17, 96);
+  const int m6a = e.add_buf(17, 17, 192), m6b = e.add_buf(17, 17, 192);
+  const int x17[3] = {e.add_buf(8, 8, 896), e.add_buf(8, 8, 896), e.add_buf(8, 8, 896)};
+  const int t17a = e.add_buf(8, 8, 128), t17b = e.add_buf(8, 8, 128), cat17 = e.add_buf(8, 8, 256);
+  const int m7a = e.add_buf(8, 8, 768), m7b = e.add_buf(8, 8, 256);
+  const int x8[3] = {e.add_buf(3, 3, 1792), e.add_buf(3, 3, 1792), e.add_buf(3, 3, 1792)};
+  const int t8a = e.add_buf(3, 3, 192), t8b = e.add_buf(3, 3, 192), cat8 = e.add_buf(3, 3, 384);
+  const int pool = e.add_buf(1, 1, 1792);
+
+  { Op op; op.kind = Op::PACK; op.a = b_in; e.ops.push_back(op); }
+
+  auto simple = [&](const std::string& name, int xb, int xoff, int cin, int cin_pad, int cout, int kh, int kw, int st,
+                    int ph, int pw, int ob, int ooff, int cout_pad = 0) -> int {
+    ConvSpec s;
+    s.name = name; s.x_buf = xb; s.x_coff = xoff; s.cin = cin; s.cin_pad = cin_pad;
+    s.KH = kh; s.KW = kw; s.sh = s.sw = st; s.ph = ph; s.pw = pw;
+    s.pieces.resize(1);
+    if (!basic_piece(wm, name, cin, cout, kh, kw, s.pieces[0], cout_pad))
+      return fail(VNF_E_MISSING, "missing weight: " + wm.missing);
+    const int cp = cout_pad ? cout_pad : cout;
+    s.segs.push_back({0, cp, ob, ooff});
+    return add_conv(e, s);
+  };
+  // fused 1x1 reducers of several branches reading the same input: one GEMM, columns routed
+  auto fused1x1 = [&](const std::string& name, std::vector<std::string> prefixes, int xb, int cin, int cout_each,
+                      std::vector<SegSpec> segs) -> int {
+    ConvSpec s;
+    s.name = name; s.x_buf = xb; s.cin = s.cin_pad = cin;
+    s.pieces.resize(prefixes.size());
+    for (size_t i = 0; i < prefixes.size(); ++i)
+      if (!basic_piece(wm, prefixes[i], cin, cout_each, 1, 1, s.pieces[i]))
+        return fail(VNF_E_MISSING, "missing weight: " + wm.missing);
+    s.segs = segs;
+    return add_conv(e, s);
+  };
+  // block-output 1x1 conv with bias, scaled residual and optional ReLU
+  // (inception_resnet_v1.py:63-67): relu(conv(cat)*scale + x) == relu(conv_{w*scale} + b*scale + x)
+  auto up = [&](const std::string& p, int cat, int cin, int cout, float scale, int xin, int xout, bool relu) -> int {
+    ConvSpec s;
+    s.name = p + ".conv2d"; s.x_buf = cat; s.cin = s.cin_pad = cin;
+    s.pieces.resize(1);
+    Piece& pc = s.pieces[0];
+    pc.w = wm.get(p + ".conv2d.weight", (int64_t)cout * cin);
+    const float* b = wm.get(p + ".conv2d.bias", cout);
+    if (!pc.w || !b) return fail(VNF_E_MISSING, "missing weight: " + wm.missing);
+    pc.cout = pc.cout_pad = cout;
+    pc.scale.assign(cout, scale);
+    pc.bias.resize(cout);
+    for (int i = 0; i < cout; ++i) pc.bias[i] = b[i] * scale;
+    s.segs.push_back({0, cout, xout, 0});
+    s.res_buf = xin;
+    s.act = relu ? ACT_RELU : ACT_NONE;
+    return add_conv(e, s);
+  };
+
+  // ---- stem (inception_resnet_v1.py:281-287)
+  TRY(simple("conv2d_1a", b_in, 0, 3, 8, 32, 3, 3, 2, 0, 0, b_1a, 0));
+  TRY(simple("conv2d_2a", b_1a, 0, 32, 32, 32, 3, 3, 1, 0, 0, b_2a, 0));
+  TRY(simple("conv2d_2b", b_2a, 0, 32, 32, 64, 3, 3, 1, 1, 1, b_2b, 0));
+  add_maxpool(e, b_2b, b_3a, 0);
+  TRY(simple("conv2d_3b", b_3a, 0, 64, 64, 80, 1, 1, 1, 0, 0, b_3b, 0, 96));
+  TRY(simple("conv2d_4a", b_3b, 0, 80, 96, 192, 3, 3, 1, 0, 0, b_4a, 0));
+  TRY(simple("conv2d_4b", b_4a, 0, 192, 192, 256, 3, 3, 2, 0, 0, x35[0], 0));
+  const int stem_end = (int)e.ops.size();
+  e.taps["conv2d_1a"] = {b_1a, 0, 32}; e.taps["conv2d_2a"] = {b_2a, 0, 32}; e.taps["conv2d_2b"] = {b_2b, 0, 64};
+  e.taps["maxpool_3a"] = {b_3a, 0, 64}; e.taps["conv2d_3b"] = {b_3b, 0, 80}; e.taps["conv2d_4a"] = {b_4a, 0, 192};
+  e.taps["conv2d_4b"] = {x35[0], 0, 256};
+
+  // ---- repeat_1: 5 x Block35 (36-67)
+  int cur = 0;
+  for (int i = 0; i < 5; ++i) {
+    const std::string p = "repeat_1." + std::to_string(i);
+    const int X = x35[cur], Y = x35[cur == 1 ? 2 : 1];
+    TRY(fused1x1(p + ".reduce", {p + ".branch0", p + ".branch1.0", p + ".branch2.0"}, X, 256, 32,
+                 {{0, 32, cat35, 0}, {32, 96, t35a, 0}}));
+    TRY(simple(p + ".branch1.1", t35a, 0, 32, 32, 32, 3, 3, 1, 1, 1, cat35, 32));
+    TRY(simple(p + ".branch2.1", t35a, 32, 32, 32, 32, 3, 3, 1, 1, 1, t35b, 0));
+    TRY(simple(p + ".branch2.2", t35b, 0, 32, 32, 32, 3, 3, 1, 1, 1, cat35, 64));
+    TRY(up(p, cat35, 96, 256, 0.17f, X, Y, true));
+    cur = (cur == 1 ? 2 : 1);
+  }
+  e.taps["repeat_1"] = {x35[cur], 0, 256};
+  // ---- mixed_6a (129-149)
+  {
+    const int X = x35[cur], O = x17[0];
+    TRY(simple("mixed_6a.branch0", X, 0, 256, 256, 384, 3, 3, 2, 0, 0, O, 0));
+    TRY(simple("mixed_6a.branch1.0", X, 0, 256, 256, 192, 1, 1, 1, 0, 0, m6a, 0));
+    TRY(simple("mixed_6a.branch1.1", m6a, 0, 192, 192, 192, 3, 3, 1, 1, 1, m6b, 0));
+    TRY(simple("mixed_6a.branch1.2", m6b, 0, 192, 192, 256, 3, 3, 2, 0, 0, O, 384));
+    add_maxpool(e, X, O, 640);
+  }
+  e.taps["mixed_6a"] = {x17[0], 0, 896};
+  // ---- repeat_2: 10 x Block17 (70-95)
+  cur = 0;
+  for (int i = 0; i < 10; ++i) {
+    const std::string p = "repeat_2." + std::to_string(i);
+    const int X = x17[cur], Y = x17[cur == 1 ? 2 : 1];
+    TRY(fused1x1(p + ".reduce", {p + ".branch0", p + ".branch1.0"}, X, 896, 128,
+                 {{0, 128, cat17, 0}, {128, 256, t17a, 0}}));
+    TRY(simple(p + ".branch1.1", t17a, 0, 128, 128, 128, 1, 7, 1, 0, 3, t17b, 0));
+    TRY(simple(p + ".branch1.2", t17b, 0, 128, 128, 128, 7, 1, 1, 3, 0, cat17, 128));
+    TRY(up(p, cat17, 256, 896, 0.10f, X, Y, true));
+    cur = (cur == 1 ? 2 : 1);
+  }
+  e.taps["repeat_2"] = {x17[cur], 0, 896};
+  // ---- mixed_7a (152-181)
+  {
+    const int X = x17[cur], O = x8[0];
+    TRY(fused1x1("mixed_7a.reduce", {"mixed_7a.branch0.0", "mixed_7a.branch1.0", "mixed_7a.branch2.0"}, X, 896, 256,
+                 {{0, 768, m7a, 0}}));
+    TRY(simple("mixed_7a.branch0.1", m7a, 0, 256, 256, 384, 3, 3, 2, 0, 0, O, 0));
+    TRY(simple("mixed_7a.branch1.1", m7a, 256, 256, 256, 256, 3, 3, 2, 0, 0, O, 384));
+    TRY(simple("mixed_7a.branch2.1", m7a, 512, 256, 256, 256, 3, 3, 1, 1, 1, m7b, 0));
+    TRY(simple("mixed_7a.branch2.2", m7b, 0, 256, 256, 256, 3, 3, 2, 0, 0, O, 640));
+    add_maxpool(e, X, O, 896);
+  }
+  e.taps["mixed_7a"] = {x8[0], 0, 1792};
+  // ---- repeat_3 (5 x Block8, scale 0.2) + block8 (scale 1, no ReLU) (98-126, 247-254)
+  cur = 0;
+  for (int i = 0; i < 6; ++i) {
+    const std::string p = i < 5 ? "repeat_3." + std::to_string(i) : std::string("block8");
+    const int X = x8[cur], Y = x8[cur == 1 ? 2 : 1];
+    TRY(fused1x1(p + ".reduce", {p + ".branch0", p + ".branch1.0"}, X, 1792, 192,
+                 {{0, 192, cat8, 0}, {192, 384, t8a, 0}}));
+    TRY(simple(p + ".branch1.1", t8a, 0, 192, 192, 192, 1, 3, 1, 0, 1, t8b, 0));
+    TRY(simple(p + ".branch1.2", t8b, 0, 192, 192, 192, 3, 1, 1, 1, 0, cat8, 192));
+    TRY(up(p, cat8, 384, 1792, i < 5 ? 0.20f : 1.0f, X, Y, i < 5));
+    cur = (cur == 1 ? 2 : 1);
+    if (i == 4) e.taps["repeat_3"] = {x8[cur], 0, 1792};
+  }
+  e.taps["block8"] = {x8[cur], 0, 1792};
+  // ---- tail (294-302): avgpool -> last_linear (no bias) -> last_bn (eps 1e-3) -> L2 normalise
+  { Op op; op.kind = Op::AVGPOOL; op.a = x8[cur]; op.b = pool; e.ops.push_back(op); }
+  {
+    ConvSpec s;
+    s.name = "last_linear"; s.x_buf = pool; s.cin = s.cin_pad = 1792;
+    s.pieces.resize(1);
+    Piece& pc = s.pieces[0];
+    pc.w = wm.get("last_linear.weight", 512 * 1792);
+    pc.cout = pc.cout_pad = 512;
+    NEED(pc.w && bn_fold(wm, "last_bn", 512, 1e-3f, pc.scale, pc.bias));
+    s.segs.push_back({0, 512, -2, 0});
+    s.act = ACT_NONE; s.out_f32 = 1;
+    TRY(add_conv(e, s));
+  }
+  { Op op; op.kind = Op::L2NORM; e.ops.push_back(op); }
+
+  int chunk = 64;
+  if (const char* c = getenv("VNF_STEM_CHUNK")) chunk = atoi(c) > 0 ? atoi(c) : chunk;
+  e.groups.push_back({0, stem_end, chunk});
+  e.groups.push_back({stem_end, (int)e.ops.size(), 1 << 30});
+  return VNF_OK;
+}
+
+int build_ir100(Encoder& e, WeightMap& wm) {
+  (void)e; (void)wm;
+  return fail(VNF_E_INVALID, "IR-100 plan not built yet");
+}
+
+// ---------------------------------------------------------------------------------------------
+int Encoder::run(const void* x, int n, int x_dtype, float* out, hipStream_t s) {
+  if (n < 0 || n > max_batch) return fail(VNF_E_CAPACITY, "batch exceeds max_batch");
+  if (n == 0) return VNF_OK;
+  const int es = dtype_size(dtype);
+  const int xes = dtype_size(x_dtype);
+  for (const Group& g : groups) {
+    const int step = g.chunk < n ? g.chunk : n;
+    for (int n0 = 0; n0 < n; n0 += step) {
+      const int nn = (n - n0) < step ? (n - n0) : step;
+      for (int oi = g.first; oi < g.last; ++oi) {
+        const Op& op = ops[oi];
+        switch (op.kind) {
+          case Op::PACK: {
+            const Buf& b = bufs[op.a];
+            const char* src = (const char*)x + (size_t)n0 * 3 * in_size * in_size * xes;
+            VNF_HIP(launch_pack_input(src, x_dtype, b.ptr + (size_t)n0 * b.elems_per_image() * es, dtype, nn,
+                                      in_size * in_size, s));
+            break;
+          }
+          case Op::CONV: {
+            const ConvLayer& L = convs[op.a];
+            const Buf& xb = bufs[L.x_buf];
+            ConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.dtype = dtype;
+            a.x = xb.ptr + ((size_t)n0 * xb.elems_per_image() + L.x_coff) * es;
+            a.ldx = xb.C; a.H = L.H; a.W = L.W; a.Cin = L.cin; a.Ho = L.Ho; a.Wo = L.Wo;
+            a.KH = L.KH; a.KW = L.KW; a.sh = L.sh; a.sw = L.sw; a.ph = L.ph; a.pw = L.pw;
+            a.w = L.w; a.K = L.K; a.Kpad = L.Kpad; a.bias = L.bias; a.ncls = L.ncls; a.cout_pad = L.cout_pad;
+            a.ktab = L.ktab; a.M = nn * L.Ho * L.Wo; a.Cout = L.cout; a.nseg = L.nseg;
+            for (int i = 0; i < L.nseg; ++i) {
+              a.seg[i].c0 = L.seg[i].c0; a.seg[i].c1 = L.seg[i].c1;
+              if (L.seg[i].buf == -2) {
+                a.seg[i].ptr = emb_raw + (size_t)n0 * 512;
+                a.seg[i].ld = 512;
+              } else {
+                const Buf& ob = bufs[L.seg[i].buf];
+                a.seg[i].ptr = ob.ptr + ((size_t)n0 * ob.elems_per_image() + L.seg[i].coff) * (L.out_f32 ? 4 : es);
+                a.seg[i].ld = ob.C;
+              }
+            }
+            if (L.res_buf >= 0) {
+              const Buf& rb = bufs[L.res_buf];
+              a.res = rb.ptr + ((size_t)n0 * rb.elems_per_image() + L.res_coff) * es;
+              a.ldres = rb.C;
+            }
+            a.act = L.act; a.slope = L.slope; a.out_f32 = L.out_f32;
+            hipError_t err = launch_conv(a, s);
+            if (err != hipSuccess) return fail(VNF_E_HIP, L.name + ": " + hipGetErrorString(err));
+            break;
+          }
+          case Op::MAXPOOL: {
+            const Buf& ib = bufs[op.a];
+            const Buf& ob = bufs[op.b];
+            VNF_HIP(launch_maxpool3s2(ib.ptr + (size_t)n0 * ib.elems_per_image() * es, ib.C,
+                                      ob.ptr + ((size_t)n0 * ob.elems_per_image() + op.c) * es, ob.C, dtype, nn, ib.H,
+                                      ib.W, ib.C, s));
+            break;
+          }
+          case Op::AVGPOOL: {
+            const Buf& ib = bufs[op.a];
+            const Buf& ob = bufs[op.b];
+            VNF_HIP(launch_avgpool(ib.ptr + (size_t)n0 * ib.elems_per_image() * es, ib.C,
+                                   ob.ptr + (size_t)n0 * ob.elems_per_image() * es, dtype, nn, ib.H * ib.W, ib.C, s));
+            break;
+          }
+          case Op::L2NORM:
+            VNF_HIP(launch_l2norm(emb_raw + (size_t)n0 * 512, out + (size_t)n0 * 512, nn, 512, s));
+            break;
+        }
+      }
+    }
+  }
+  return VNF_OK;
+}
+
+}  // namespace vnf

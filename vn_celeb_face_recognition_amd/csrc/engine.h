@@ -1,0 +1,97 @@
+// Host-side engine shared by the encoder / classifier / detector handles of libvnface.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/vnface.h"
+#include "kernels.h"
+
+namespace vnf {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define VNF_HIP(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return ::vnf::fail(VNF_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+  } while (0)
+
+struct HandleBase {
+  int kind = 0;  // 1 encoder, 2 mlp, 3 mtcnn
+  int device = 0;
+  std::vector<void*> allocs;  // device allocations owned by the handle
+  virtual ~HandleBase();
+  void* dalloc(size_t bytes);  // hipMalloc + bookkeeping (nullptr on failure, error set)
+  void* upload(const void* host, size_t bytes);
+};
+
+// state_dict lookup -----------------------------------------------------------------------
+struct WeightMap {
+  std::unordered_map<std::string, const vnf_tensor_desc*> m;
+  std::string missing;
+  WeightMap(const vnf_tensor_desc* w, int n);
+  const float* get(const std::string& name, int64_t numel);  // nullptr (+missing recorded) if absent / wrong size
+  bool has(const std::string& name) const { return m.count(name) != 0; }
+};
+
+// host float -> storage dtype ----------------------------------------------------------------
+void convert_to(int dtype, const float* src, void* dst, size_t n);
+
+// ---------------------------------------------------------------------------------------------
+// Encoder: a static plan of convolutions / pools over NHWC buffers.
+struct Buf {
+  int H, W, C;
+  size_t elems_per_image() const { return (size_t)H * W * C; }
+  char* ptr = nullptr;
+};
+
+struct ConvLayer {
+  std::string name;
+  int x_buf, x_coff, cin;  // cin = padded channels consumed
+  int H, W, Ho, Wo, KH, KW, sh, sw, ph, pw;
+  void* w = nullptr;
+  float* bias = nullptr;
+  float* slope = nullptr;
+  int4* ktab = nullptr;
+  int K, Kpad, cout, cout_pad, ncls = 1;
+  int nseg = 0;
+  struct { int c0, c1, buf, coff; } seg[4];
+  int res_buf = -1, res_coff = 0;
+  int act = ACT_NONE, out_f32 = 0;
+  double macs_alg = 0, macs_exec = 0;  // per image
+};
+
+struct Op {
+  enum Kind { PACK, CONV, MAXPOOL, AVGPOOL, L2NORM } kind;
+  int a = 0, b = 0, c = 0, d = 0, e = 0;  // meaning per kind (see engine.cpp)
+};
+
+struct Group { int first, last, chunk; };  // ops [first,last) run per `chunk` images (L3 residency)
+
+struct Tap { int buf, coff, C; };
+
+struct Encoder : HandleBase {
+  int arch, dtype, max_batch, in_size;
+  std::vector<Buf> bufs;
+  std::vector<ConvLayer> convs;
+  std::vector<Op> ops;
+  std::vector<Group> groups;
+  std::unordered_map<std::string, Tap> taps;
+  float* emb_raw = nullptr;  // (max_batch,512) fp32 before the final normalisation
+  double macs_alg = 0, macs_exec = 0;
+
+  int add_buf(int H, int W, int C);
+  int finalize();  // allocate buffers
+  int run(const void* x, int n, int x_dtype, float* out, hipStream_t s);
+};
+
+int build_irv1(Encoder& e, WeightMap& wm);
+int build_ir100(Encoder& e, WeightMap& wm);
+
+}  // namespace vnf

@@ -1,0 +1,64 @@
+// Internal launch interface between the engine (engine.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vnf {
+
+enum DType { F32 = 0, BF16 = 1, F16 = 2 };
+inline int dtype_size(int dt) { return dt == F32 ? 4 : 2; }
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_PRELU = 2 };
+
+struct ConvSeg {   // output columns [c0,c1) of the GEMM go to ptr (already channel-offset), pixel stride ld
+  int c0, c1;
+  void* ptr;
+  int ld;
+};
+
+// One implicit-GEMM convolution over NHWC activations.
+//   out[m][co] = act( sum_k x[pix(m) + tap(k)] * w[co][k] + bias[cls(m)][co] + res[m][co] )
+// m = (n*Ho + ho)*Wo + wo; k = (kh*KW + kw)*Cin + c.
+struct ConvArgs {
+  int dtype;            // compute/storage dtype of x, w, res, out (unless out_f32)
+  const void* x;        // channel-offset base of the input slice
+  int ldx;              // pixel stride of x in elements
+  int H, W, Cin;        // Cin = channels consumed (multiple of the 16-byte chunk)
+  int Ho, Wo;
+  int KH, KW, sh, sw, ph, pw;
+  const void* w;        // packed [Cout_pad][Kpad], k-order (kh,kw,c)
+  int K, Kpad;
+  const float* bias;    // [ncls][Cout_pad]
+  int ncls;             // 1, or 9 for the border-class bias of a folded pre-conv BatchNorm
+  int cout_pad;         // row stride of bias / slope tables
+  const int4* ktab;     // per 16-byte k-chunk: {element offset, dh, dw, valid}
+  int M, Cout;
+  int nseg;
+  ConvSeg seg[4];
+  const void* res;      // optional residual [M][ldres] (channel-offset base)
+  int ldres;
+  int act;
+  const float* slope;   // PReLU slopes [Cout_pad]
+  int out_f32;          // store fp32 instead of dtype
+  int bm, bn;           // tile choice (0 = heuristic)
+};
+
+hipError_t launch_conv(const ConvArgs& a, hipStream_t s);
+
+// NCHW (n,3,S,S) of x_dtype -> NHWC8 of dtype (channels 3..7 zero)
+hipError_t launch_pack_input(const void* x, int x_dtype, void* out, int dtype, int n, int hw, hipStream_t s);
+
+// 3x3 stride-2 max pool, floor mode, NHWC slice -> NHWC slice
+hipError_t launch_maxpool3s2(const void* x, int ldx, void* y, int ldy, int dtype, int n, int H, int W, int C,
+                             hipStream_t s);
+
+// global average pool NHWC (n,HW,C) -> (n,C)
+hipError_t launch_avgpool(const void* x, int ldx, void* y, int dtype, int n, int HW, int C, hipStream_t s);
+
+// rows of fp32 (n,C): y = x / max(||x||_2, 1e-12)
+hipError_t launch_l2norm(const float* x, float* y, int n, int C, hipStream_t s);
+
+// NHWC slice (dtype) -> NCHW fp32 (for taps / debugging)
+hipError_t launch_nhwc_to_nchw_f32(const void* x, int ldx, int dtype, float* y, int n, int HW, int C, hipStream_t s);
+
+}  // namespace vnf
