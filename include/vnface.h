@@ -86,6 +86,10 @@ int vnf_embed(vnf_handle h, const void* x, int n, int x_dtype, float* emb_out, v
  * Synchronises the stream.  name is a reference module name ("conv2d_4b", "repeat_2", ...). */
 int vnf_encoder_tap(vnf_handle h, const char* name, int n, float* host_out, int64_t capacity,
                     int64_t shape_out[4]);
+/* vnf_embed with per-launch device timing (HIP events between ops; synchronises).  Writes a
+ * text table (one line per plan op: shape, ms, TFLOP/s) into report. */
+int vnf_encoder_profile(vnf_handle h, const void* x, int n, int x_dtype, float* emb_out, void* stream,
+                        char* report, int64_t capacity);
 /* FLOPs of one image through the loaded encoder as the kernels execute it (padded K / channels
  * included) and as the algorithm defines it; used by bench.py for the roofline line. */
 int vnf_encoder_flops(vnf_handle h, double* algorithmic, double* executed);

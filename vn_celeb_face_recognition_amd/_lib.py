@@ -40,6 +40,7 @@ SIGNATURES = {
     "vnf_encoder_create": (_I, [_I, ctypes.POINTER(TensorDesc), _I, _I, _I, ctypes.POINTER(_P)]),
     "vnf_embed": (_I, [_P, _P, _I, _I, _P, _P]),
     "vnf_encoder_tap": (_I, [_P, ctypes.c_char_p, _I, _P, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
+    "vnf_encoder_profile": (_I, [_P, _P, _I, _I, _P, _P, ctypes.c_char_p, ctypes.c_int64]),
     "vnf_encoder_flops": (_I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "vnf_mlp_create": (_I, [ctypes.POINTER(TensorDesc), _I, _I, _I, _I, ctypes.POINTER(_P)]),
     "vnf_classify": (_I, [_P, _P, _I, _P, _P, _P, _P]),

@@ -106,6 +106,20 @@ int vnf_encoder_tap(vnf_handle h, const char* name, int n, float* host_out, int6
   API_GUARD_END
 }
 
+int vnf_encoder_profile(vnf_handle h, const void* x, int n, int x_dtype, float* emb_out, void* stream, char* report,
+                        int64_t capacity) {
+  API_GUARD_BEGIN
+  Encoder* e = as_encoder(h);
+  if (!e || !report || capacity <= 0) return fail(VNF_E_INVALID, "bad argument");
+  std::string rep;
+  int r = e->run(x, n, x_dtype, emb_out, (hipStream_t)stream, &rep);
+  if (r != VNF_OK) return r;
+  strncpy(report, rep.c_str(), (size_t)capacity - 1);
+  report[capacity - 1] = 0;
+  return VNF_OK;
+  API_GUARD_END
+}
+
 int vnf_encoder_flops(vnf_handle h, double* algorithmic, double* executed) {
   API_GUARD_BEGIN
   Encoder* e = as_encoder(h);

@@ -422,17 +422,27 @@ int build_ir100(Encoder& e, WeightMap& wm) {
 }
 
 // ---------------------------------------------------------------------------------------------
-int Encoder::run(const void* x, int n, int x_dtype, float* out, hipStream_t s) {
+int Encoder::run(const void* x, int n, int x_dtype, float* out, hipStream_t s, std::string* report) {
   if (n < 0 || n > max_batch) return fail(VNF_E_CAPACITY, "batch exceeds max_batch");
   if (n == 0) return VNF_OK;
   const int es = dtype_size(dtype);
   const int xes = dtype_size(x_dtype);
+  std::vector<hipEvent_t> prof_ev;
+  std::vector<int> prof_op, prof_n;
   for (const Group& g : groups) {
     const int step = g.chunk < n ? g.chunk : n;
     for (int n0 = 0; n0 < n; n0 += step) {
       const int nn = (n - n0) < step ? (n - n0) : step;
       for (int oi = g.first; oi < g.last; ++oi) {
         const Op& op = ops[oi];
+        if (report) {
+          hipEvent_t e0;
+          VNF_HIP(hipEventCreate(&e0));
+          VNF_HIP(hipEventRecord(e0, s));
+          prof_ev.push_back(e0);
+          prof_op.push_back(oi);
+          prof_n.push_back(nn);
+        }
         switch (op.kind) {
           case Op::PACK: {
             const Buf& b = bufs[op.a];
@@ -494,6 +504,39 @@ int Encoder::run(const void* x, int n, int x_dtype, float* out, hipStream_t s) {
         }
       }
     }
+  }
+  if (report) {
+    // per-op device time (events between consecutive launches on the stream), summed over chunks
+    hipEvent_t e_end;
+    VNF_HIP(hipEventCreate(&e_end));
+    VNF_HIP(hipEventRecord(e_end, s));
+    VNF_HIP(hipEventSynchronize(e_end));
+    prof_ev.push_back(e_end);
+    std::vector<double> ms(ops.size(), 0.0);
+    for (size_t i = 0; i + 1 < prof_ev.size(); ++i) {
+      float t = 0;
+      VNF_HIP(hipEventElapsedTime(&t, prof_ev[i], prof_ev[i + 1]));
+      ms[prof_op[i]] += t;
+    }
+    for (auto ev : prof_ev) (void)hipEventDestroy(ev);
+    char line[512];
+    double total = 0;
+    for (size_t oi = 0; oi < ops.size(); ++oi) {
+      const Op& op = ops[oi];
+      total += ms[oi];
+      if (op.kind == Op::CONV) {
+        const ConvLayer& L = convs[op.a];
+        const double gf = 2.0 * L.macs_alg * n / 1e9;
+        snprintf(line, sizeof line, "%-28s conv M/img=%-6d N=%-5d K=%-5d %dx%d s%d  %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n",
+                 L.name.c_str(), L.Ho * L.Wo, L.cout, L.K, L.KH, L.KW, L.sh, ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
+      } else {
+        static const char* kn[] = {"pack", "conv", "maxpool", "avgpool", "l2norm"};
+        snprintf(line, sizeof line, "%-28s %-8s %60s %8.4f ms\n", "", kn[op.kind], "", ms[oi]);
+      }
+      *report += line;
+    }
+    snprintf(line, sizeof line, "TOTAL %.4f ms for n=%d\n", total, n);
+    *report += line;
   }
   return VNF_OK;
 }

@@ -88,7 +88,7 @@ struct Encoder : HandleBase {
 
   int add_buf(int H, int W, int C);
   int finalize();  // allocate buffers
-  int run(const void* x, int n, int x_dtype, float* out, hipStream_t s);
+  int run(const void* x, int n, int x_dtype, float* out, hipStream_t s, std::string* report = nullptr);
 };
 
 int build_irv1(Encoder& e, WeightMap& wm);

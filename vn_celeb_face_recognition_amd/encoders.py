@@ -159,6 +159,18 @@ class _Encoder:
         _lib.check(lib.vnf_encoder_tap(h, name.encode(), n, buf.ctypes.data, total, shape))
         return buf.reshape(tuple(int(s) for s in shape))
 
+    def profile(self, x):
+        """Per-launch device-time table of one forward (text)."""
+        h = self._ensure_handle()
+        x = x.contiguous()
+        out = torch.empty((x.shape[0], 512), dtype=torch.float32, device=x.device)
+        buf = ctypes.create_string_buffer(1 << 16)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().vnf_encoder_profile(h, ctypes.c_void_p(x.data_ptr()), x.shape[0],
+                                                       _lib.torch_dtype_code(x.dtype), ctypes.c_void_p(out.data_ptr()),
+                                                       _lib.current_stream_ptr(), buf, len(buf)))
+        return buf.value.decode()
+
     def flops_per_image(self):
         h = self._ensure_handle()
         a, e = ctypes.c_double(), ctypes.c_double()
