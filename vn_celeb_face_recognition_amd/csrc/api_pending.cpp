@@ -3,9 +3,6 @@
 #include "engine.h"
 using namespace vnf;
 extern "C" {
-int vnf_mlp_create(const vnf_tensor_desc*, int, int, int, int, vnf_handle*) { return fail(VNF_E_INVALID, "vnf_mlp_create: not implemented in this build"); }
-int vnf_classify(vnf_handle, const float*, int, float*, int32_t*, float*, void*) { return fail(VNF_E_INVALID, "vnf_classify: not implemented in this build"); }
 int vnf_mtcnn_create(const vnf_tensor_desc*, int, const vnf_tensor_desc*, int, const vnf_tensor_desc*, int, const vnf_mtcnn_cfg*, vnf_handle*) { return fail(VNF_E_INVALID, "vnf_mtcnn_create: not implemented in this build"); }
 int vnf_mtcnn_detect(vnf_handle, const uint8_t*, int, int, int, int32_t*, float*, float*, float*, int, int32_t*, void*) { return fail(VNF_E_INVALID, "vnf_mtcnn_detect: not implemented in this build"); }
-int vnf_align(const uint8_t*, int, int, int, const int32_t*, const float*, const float*, int, const float*, int, uint8_t*, void*, int, void*) { return fail(VNF_E_INVALID, "vnf_align: not implemented in this build"); }
 }

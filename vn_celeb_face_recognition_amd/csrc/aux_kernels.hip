@@ -153,6 +153,46 @@ hipError_t launch_l2norm(const float* x, float* y, int n, int C, hipStream_t s) 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- log_softmax + argmax + prob
+// one wave per row of logits (mlp_model.py:14 log_softmax; demo_image.py:125-129 argmax, exp)
+__global__ void logsoftmax_argmax_kernel(const float* __restrict__ logits, int ld, int C, int n,
+                                         float* __restrict__ logp, int32_t* __restrict__ amax,
+                                         float* __restrict__ prob) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float* x = logits + (size_t)row * ld;
+  float m = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) {
+    const float v = x[c];
+    if (v > m) { m = v; mi = c; }   // first occurrence within the lane's stride
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(m, o);
+    const int oi = __shfl_xor(mi, o);
+    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+  }
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += expf(x[c] - m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float ls = logf(s);
+  if (logp)
+    for (int c = lane; c < C; c += 64) logp[(size_t)row * C + c] = (x[c] - m) - ls;
+  if (lane == 0) {
+    if (amax) amax[row] = mi;
+    if (prob) prob[row] = expf(-ls);  // exp(logp[argmax]) with logp[argmax] = 0 - log(sum)
+  }
+}
+
+hipError_t launch_logsoftmax_argmax(const float* logits, int ld, int C, int n, float* logp, int32_t* amax, float* prob,
+                                    hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(logsoftmax_argmax_kernel, dim3((n + 3) / 4), dim3(256), 0, s, logits, ld, C, n, logp, amax, prob);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- NHWC slice -> NCHW fp32 (taps)
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, int ldx, float* __restrict__ y, int n, int HW, int C) {

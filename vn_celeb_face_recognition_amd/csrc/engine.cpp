@@ -416,6 +416,20 @@ int build_irv1(Encoder& e, WeightMap& wm) {
   return VNF_OK;
 }
 
+// A linear layer as a 1x1 convolution over a 1x1 "image" (used by the MLP classifier).
+int add_linear(Encoder& e, const std::string& name, const float* w, const float* b, int cin, int cout, int cout_pad,
+               int x_buf, int o_buf, int act) {
+  ConvSpec s;
+  s.name = name; s.x_buf = x_buf; s.cin = s.cin_pad = cin;
+  s.pieces.resize(1);
+  Piece& pc = s.pieces[0];
+  pc.w = w; pc.cout = cout; pc.cout_pad = cout_pad;
+  pc.bias.assign(b, b + cout);
+  s.segs.push_back({0, cout_pad, o_buf, 0});
+  s.act = act;
+  return add_conv(e, s);
+}
+
 int build_ir100(Encoder& e, WeightMap& wm) {
   (void)e; (void)wm;
   return fail(VNF_E_INVALID, "IR-100 plan not built yet");

@@ -58,6 +58,11 @@ hipError_t launch_avgpool(const void* x, int ldx, void* y, int dtype, int n, int
 // rows of fp32 (n,C): y = x / max(||x||_2, 1e-12)
 hipError_t launch_l2norm(const float* x, float* y, int n, int C, hipStream_t s);
 
+// rows of fp32 logits (n, ld >= C): log_softmax over the first C columns, argmax (first
+// occurrence) and exp(logp[argmax])
+hipError_t launch_logsoftmax_argmax(const float* logits, int ld, int C, int n, float* logp, int32_t* amax, float* prob,
+                                    hipStream_t s);
+
 // NHWC slice (dtype) -> NCHW fp32 (for taps / debugging)
 hipError_t launch_nhwc_to_nchw_f32(const void* x, int ldx, int dtype, float* y, int n, int HW, int C, hipStream_t s);
 

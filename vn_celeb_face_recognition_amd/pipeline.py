@@ -1,0 +1,180 @@
+"""Host-side mirror of the reference's pipeline glue (same names, argument meaning and error
+behaviour), with the arithmetic in libvnface.so:
+
+  center_point_dict, alignment      <- /root/reference/align_face.py:12-48, 51-57
+  transforms_default                <- /root/reference/data_loader/__init__.py:27-34,52-56
+  find_embedding                    <- /root/reference/demo_image.py:30-34
+  recognize_celeb                   <- /root/reference/demo_image.py:50-76
+  identify_person                   <- /root/reference/demo_image.py:113-147
+  get_face_from_boxes               <- /root/reference/demo_image.py:174-199
+  move_landmark_to_box              <- /root/reference/demo_image.py:236-239
+  parallel_detect_and_align         <- /root/reference/demo_image.py:273-306
+
+`FacePipeline` is the build's resident fast path: frames are uploaded once, boxes, landmarks,
+aligned faces and embeddings stay in HBM (the reference round-trips through the host between
+detection, OpenCV alignment and embedding: SURVEY.md 3.1), only names / boxes come back.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# align_face.py:12-48 (ArcFace 5-point templates; values are data)
+center_point_dict = {
+    '(96, 112)': np.array([[30.2946, 51.6963], [65.5318, 51.5014], [48.0252, 71.7366],
+                           [33.5493, 92.3655], [62.7299, 92.2041]], dtype=np.float32),
+    '(112, 112)': np.array([[38.2946, 51.6963], [73.5318, 51.5014], [56.0252, 71.7366],
+                            [41.5493, 92.3655], [70.7299, 92.2041]], dtype=np.float32),
+    '(150, 150)': np.array([[51.287415, 69.23612], [98.48009, 68.97509], [75.03375, 96.075806],
+                            [55.646385, 123.7038], [94.72754, 123.48763]], dtype=np.float32),
+    '(160, 160)': np.array([[54.706573, 73.85186], [105.045425, 73.573425], [80.036, 102.48086],
+                            [59.356144, 131.95071], [101.04271, 131.72014]], dtype=np.float32),
+    '(224, 224)': np.array([[76.589195, 103.3926], [147.0636, 103.0028], [112.0504, 143.4732],
+                            [83.098595, 184.731], [141.4598, 184.4082]], dtype=np.float32),
+}
+
+
+def _dev(device=None):
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("the alignment / recognition path runs on MI355X only (no CPU path)")
+    return device
+
+
+def align_faces_device(frames_dev, frame_idx, boxes, points, template, size, want_u8=True, norm_dtype=None):
+    """vnf_align on resident frames.  frames_dev: (B,H,W,3) u8 cuda; frame_idx (n,) int32, boxes (n,4),
+    points (n,5,2) fp32 (cuda or host).  Returns (faces_u8 (n,S,S,3) or None, faces_norm (n,3,S,S) or None)."""
+    dev = frames_dev.device
+    n = int(boxes.shape[0])
+    B, H, W, _ = frames_dev.shape
+    fi = torch.as_tensor(frame_idx, dtype=torch.int32).to(dev).contiguous()
+    bx = torch.as_tensor(boxes, dtype=torch.float32).to(dev).contiguous().view(n, 4)
+    pt = torch.as_tensor(points, dtype=torch.float32).to(dev).contiguous().view(n, 10)
+    tm = np.ascontiguousarray(template, dtype=np.float32).reshape(10)
+    u8 = torch.empty((n, size, size, 3), dtype=torch.uint8, device=dev) if want_u8 else None
+    nm = torch.empty((n, 3, size, size), dtype=norm_dtype, device=dev) if norm_dtype is not None else None
+    if n:
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().vnf_align(
+                ctypes.c_void_p(frames_dev.data_ptr()), B, H, W, ctypes.c_void_p(fi.data_ptr()),
+                ctypes.c_void_p(bx.data_ptr()), ctypes.c_void_p(pt.data_ptr()), n, tm.ctypes.data, size,
+                ctypes.c_void_p(u8.data_ptr()) if want_u8 else None,
+                ctypes.c_void_p(nm.data_ptr()) if nm is not None else None,
+                _lib.torch_dtype_code(norm_dtype) if nm is not None else 0, _lib.current_stream_ptr()))
+    return u8, nm
+
+
+def alignment(cv_img, src, dst, dst_w, dst_h, device=None):
+    """align_face.py:51-57: warp `cv_img` (HxWx3 u8) so landmarks `dst` land on template `src`."""
+    if dst_w != dst_h:
+        raise NotImplementedError("square targets only (every template of center_point_dict the demos use)")
+    dev = _dev(device)
+    img = torch.from_numpy(np.ascontiguousarray(cv_img)).to(dev).unsqueeze(0)
+    h, w = cv_img.shape[:2]
+    # the whole image is the crop: box (0,0,w-1,h-1) -> crop [0,w) x [0,h), landmark shift 0
+    box = np.array([[0.0, 0.0, w - 1, h - 1]], dtype=np.float32)
+    u8, _ = align_faces_device(img, np.zeros(1, np.int32), box, np.asarray(dst, np.float32).reshape(1, 5, 2), src, dst_w)
+    return u8[0].cpu().numpy()
+
+
+def transforms_default(face_u8):
+    """data_loader/__init__.py:27-34,52-56 (host tensor, as the reference returns)."""
+    x = (np.float32(face_u8) - 127.5) / 128
+    return torch.from_numpy(np.ascontiguousarray(np.transpose(x, (2, 0, 1))))
+
+
+def find_embedding(image_tensor, embedding_model):
+    embedding_model.eval()
+    with torch.no_grad():
+        embeddings = embedding_model(image_tensor)
+    return embeddings.detach()
+
+
+def identify_person(embeddings, classify_model, name_df, threshold):
+    """demo_image.py:113-147.  name_df: anything with ['label'] / ['name'] columns (pandas
+    DataFrame or dict of sequences)."""
+    classify_model.eval()
+    logp, amax, prob = classify_model.classify(embeddings, want_logp=False)
+    n_classes = classify_model.num_classes
+    preds = amax.cpu().numpy()
+    probs = prob.cpu().numpy()
+    filtered = []
+    for p, pr in zip(preds, probs):
+        thr = threshold if type(threshold) is float else threshold[str(int(p))]
+        filtered.append(int(p) if pr >= thr else n_classes)
+    labels = list(name_df['label'])
+    names = list(name_df['name'])
+    first = {}
+    for l, nm in zip(labels, names):
+        first.setdefault(int(l), nm)
+    return [first.get(p, 'Unknown') for p in filtered]
+
+
+def recognize_celeb(bth_alg_face_list, device, emb_model, classify_model, transforms, label2name_df, threshold):
+    """demo_image.py:50-76."""
+    alg_face_list = []
+    for x in bth_alg_face_list:
+        alg_face_list += x
+    tf_list = [transforms(face) for face in alg_face_list]
+    if len(tf_list) > 0:
+        aligned_faces_tf = torch.stack(tf_list, dim=0)
+        embeddings = find_embedding(aligned_faces_tf.to(device), emb_model)
+        names = identify_person(embeddings, classify_model, label2name_df, threshold)
+        bth_names, counter = [], 0
+        for n_face in [len(x) for x in bth_alg_face_list]:
+            bth_names.append(names[counter: counter + n_face])
+            counter += n_face
+    else:
+        bth_names = [[] for _ in range(len(bth_alg_face_list))]
+    return bth_names
+
+
+def get_face_from_boxes(image, boxes, box_requirements=None):
+    """demo_image.py:174-199 (host views, no arithmetic)."""
+    list_faces, face_idx = [], []
+    ori_h, ori_w = image.shape[:2]
+    for idx, box in enumerate(boxes):
+        x1 = max(int(box[0]), 0)
+        y1 = max(int(box[1]), 0)
+        x2 = min(int(box[2] + 1), ori_w)
+        y2 = min(int(box[3] + 1), ori_h)
+        w, h = x2 - x1, y2 - y1
+        max_dim, min_dim = max(w, h), min(w, h)
+        chosen = box_requirements is None or (min_dim > box_requirements['min_dim'] and
+                                              (max_dim / min_dim < box_requirements['box_ratio']))
+        if chosen:
+            list_faces.append(image[y1:y2, x1:x2, :])
+            face_idx.append(idx)
+    return list_faces, face_idx
+
+
+def move_landmark_to_box(box, landmark):
+    return landmark - box[:2]
+
+
+def parallel_detect_and_align(rgb_images, detection_md, center_point, target_fs, log=False):
+    """demo_image.py:273-306: returns (per-image lists of aligned (S,S,3) u8 faces, chosen boxes).
+    Frames are uploaded once; detection and the warp both read them from HBM."""
+    bth_boxes, _, bth_landmarks = detection_md.inference(rgb_images, landmark=True)
+    frames = detection_md.last_frames_device()
+    fidx, boxes, points = [], [], []
+    for i, (bx, lm) in enumerate(zip(bth_boxes, bth_landmarks)):
+        for b, l in zip(bx, lm):
+            fidx.append(i); boxes.append(b); points.append(l)
+    n = len(boxes)
+    bth_aligned_faces = [[] for _ in rgb_images]
+    bth_chosen_bb = [[] for _ in rgb_images]
+    if n:
+        u8, _ = align_faces_device(frames, np.asarray(fidx, np.int32), np.asarray(boxes, np.float32),
+                                   np.asarray(points, np.float32), center_point, target_fs[0])
+        u8 = u8.cpu().numpy()
+        for k in range(n):
+            bth_aligned_faces[fidx[k]].append(u8[k])
+            bth_chosen_bb[fidx[k]].append(boxes[k])
+    elif log:
+        print('Face not found in this image !')
+    return bth_aligned_faces, bth_chosen_bb
