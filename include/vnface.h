@@ -126,6 +126,12 @@ int vnf_mtcnn_detect(vnf_handle h, const uint8_t* frames, int b, int height, int
                      int32_t* counts, float* boxes, float* probs, float* points, int max_out,
                      int32_t* n_out, void* stream);
 
+/* staged parity hook: runs the cascade on frame 0 and copies one pyramid level (3,Hs,Ws), its
+ * P-Net face-probability map (oh,ow) and regression map (4,oh,ow) to host arrays.
+ * dims receives {Hs, Ws, oh, ow}.  Synchronises. */
+int vnf_mtcnn_debug_pnet(vnf_handle h, const uint8_t* frames, int height, int width, int level,
+                         float* level_out, float* prob_out, float* reg_out, int32_t dims[4], void* stream);
+
 /* alignment -------------------------------------------------------------------------------- */
 /* For each of n faces: crop rectangle from its box (demo_image.py:179-182), landmarks moved by
  * the float box corner (236-239), Umeyama similarity landmarks -> template (align_face.py:52-54),

@@ -183,14 +183,21 @@ def batched_nms(boxes, scores, idxs, thr):
     return keep[np.argsort(-scores[keep].astype(np.float32), kind="stable")]
 
 
-def nms_min(boxes, scores, thr):
+def nms_min(boxes, scores, thr, ties="numpy"):
     """detect_face.py:221-257 with method 'Min': areas with +1, ascending argsort, visit from the
-    back, overlap = inter / min(area_i, area_j), survivors are those with o <= thr."""
+    back, overlap = inter / min(area_i, area_j), survivors are those with o <= thr.
+
+    ties: the reference calls np.argsort(s) with NumPy's default UNSTABLE sort, so the visiting
+    order of EQUAL scores is implementation defined (it changes with array length, NumPy version
+    and the CPU's SIMD dispatch) -- and equal scores do occur: softmax saturates to exactly 1.0f
+    on clear faces.  "numpy" keeps the verbatim call (what the goldens captured in the build
+    container); "table" pins equal scores to table order (lower row first), the deterministic
+    rule the HIP kernel implements."""
     if boxes.size == 0:
         return np.zeros((0,), dtype=np.int64)
     x1, y1, x2, y2 = (boxes[:, k].copy() for k in range(4))
     area = (x2 - x1 + 1) * (y2 - y1 + 1)
-    I = np.argsort(scores)
+    I = np.argsort(scores) if ties == "numpy" else np.lexsort((-np.arange(len(scores)), scores))
     pick = []
     while I.size > 0:
         i = I[-1]
@@ -208,18 +215,17 @@ def nms_min(boxes, scores, thr):
     return np.asarray(pick, dtype=np.int64)
 
 
-def batched_nms_min(boxes, scores, idxs, thr):
+def batched_nms_min(boxes, scores, idxs, thr, ties="numpy"):
     """detect_face.py:260-274 per image (offset trick == per-image result; header)."""
     if boxes.shape[0] == 0:
         return np.zeros((0,), dtype=np.int64)
     picks = []
     for c in np.unique(idxs):
         rows = np.nonzero(idxs == c)[0]
-        picks.append(rows[nms_min(boxes[rows], scores[rows], thr)])
+        picks.append(rows[nms_min(boxes[rows], scores[rows], thr, ties)])
     keep = np.concatenate(picks)
-    # the reference runs ONE nms over offset boxes: picks come out in global score-descending
-    # order (ties: later index first, np.argsort ascending read from the back)
-    order = np.argsort(scores[keep], kind="stable")[::-1]
+    # the reference runs ONE nms over offset boxes: picks come out in global score-descending order
+    order = np.argsort(-scores[keep], kind="stable")
     return keep[order]
 
 
@@ -272,7 +278,7 @@ def _crops(imgs, image_inds, y, ey, x, ex, size):
 
 
 # ----------------------------------------------------------------------------- cascade
-def detect_face(imgs, minsize, pnet_sd, rnet_sd, onet_sd, threshold, factor, stages=None):
+def detect_face(imgs, minsize, pnet_sd, rnet_sd, onet_sd, threshold, factor, stages=None, ties="numpy"):
     """detect_face.py:25-185.  imgs: (B,H,W,3) uint8 ndarray (or a list of equal-size HWC
     arrays).  Returns (list of (n,5) boxes, list of (n,5,2) points) per image.
     `stages`, if a dict, receives the intermediate tables used by the staged parity tests."""
@@ -363,7 +369,7 @@ def detect_face(imgs, minsize, pnet_sd, rnet_sd, onet_sd, threshold, factor, sta
             boxes = bbreg(boxes, mv)
             if stages is not None:
                 stages["stage3_pre_nms"] = (boxes.copy(), image_inds.copy(), points.copy())
-            pick = batched_nms_min(boxes[:, :4], boxes[:, 4], image_inds, 0.7)
+            pick = batched_nms_min(boxes[:, :4], boxes[:, 4], image_inds, 0.7, ties)
             boxes, image_inds, points = boxes[pick], image_inds[pick], points[pick]
 
         batch_boxes, batch_points = [], []
@@ -375,12 +381,12 @@ def detect_face(imgs, minsize, pnet_sd, rnet_sd, onet_sd, threshold, factor, sta
 
 
 def mtcnn_detect(imgs, pnet_sd, rnet_sd, onet_sd, min_face_size=20, thresholds=(0.6, 0.7, 0.7),
-                 factor=0.709, select_largest=True, landmarks=True, stages=None):
+                 factor=0.709, select_largest=True, landmarks=True, stages=None, ties="numpy"):
     """mtcnn.py:318-361 + inference 511-513.  Returns per-image lists (ragged-safe: the
     reference's np.array() of ragged lists raises on NumPy >= 1.24)."""
     single = not isinstance(imgs, (list, tuple)) and np.asarray(imgs).ndim == 3
     bb, pp = detect_face(imgs, min_face_size, pnet_sd, rnet_sd, onet_sd, list(thresholds), factor,
-                         stages=stages)
+                         stages=stages, ties=ties)
     boxes, probs, points = [], [], []
     for box, point in zip(bb, pp):
         if len(box) == 0:

@@ -47,6 +47,7 @@ SIGNATURES = {
     "vnf_mtcnn_create": (_I, [ctypes.POINTER(TensorDesc), _I, ctypes.POINTER(TensorDesc), _I,
                               ctypes.POINTER(TensorDesc), _I, ctypes.POINTER(MtcnnCfg), ctypes.POINTER(_P)]),
     "vnf_mtcnn_detect": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, ctypes.POINTER(ctypes.c_int32), _P]),
+    "vnf_mtcnn_debug_pnet": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _P]),
     "vnf_align": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _P]),
 }
 

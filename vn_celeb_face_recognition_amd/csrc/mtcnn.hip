@@ -1,0 +1,1104 @@
+// MTCNN P/R/O-Net cascade on the device (gfx950), restating
+//   /root/reference/models/mtcnn_utils/detect_face.py:25-185 (detect_face) and helpers 188-306,
+//   /root/reference/models/mtcnn.py:38-49, 84-99, 138-157 (the three nets), 326-347 (area ordering).
+//
+// Everything between "frames are in HBM" and "final boxes" stays on the device: the image pyramid,
+// the three nets, threshold + compaction, all four NMS passes, box regression / squaring / padding
+// and the per-candidate crop+resize that the reference does in Python loops.  fp32 everywhere
+// (thin channels: 3..128; the path is HBM / latency bound, not FLOP bound), explicit op order
+// (built with -ffp-contract=off, FMAs only where written) so box arithmetic and IoU tests are
+// bit-identical to the fp32 numpy / torch-CPU statements of the oracle.
+//
+// Kernel map:
+//   K1 pyramid_kernel        u8 frame -> all pyramid levels (adaptive-average bins, normalised)
+//   K2 pnet_conv1_pool / pnet_conv2 / pnet_conv3_heads   (all levels and frames per launch)
+//   K3 threshold + compaction fused into pnet_conv3_heads (wave-aggregated atomic slots;
+//      order restored by the sort keys, which carry the cell index)
+//   K4 nms_scale_kernel (per level x frame, IoU 0.5), nms_image_kernel (per frame, IoU 0.7,
+//      + regress, rerec, pad), stage2_post_kernel (IoU 0.7 + bbreg + rerec + pad)
+//   K5 crop_resize_kernel    box table -> N x 3 x {24,48}^2 (area bins, also up-sampling)
+//   K6 rnet_kernel / onet_kernel   one workgroup per candidate, activations resident in LDS
+//   K7 stage3_post_kernel    landmarks, bbreg, "Min" NMS, area-descending order
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstring>
+#include <cmath>
+#include <vector>
+
+#include "engine.h"
+
+namespace vnf {
+
+constexpr int MAX_LEVELS = 24;
+constexpr int CAP_SCALE = 4096;  // candidates per (level, frame) before NMS (12-bit slot in the sort key)
+constexpr int CAP_IMG = 8192;    // candidates per frame entering the cross-scale NMS
+constexpr int KEEP = 2048;       // survivors per frame after any NMS pass (stage-2 / stage-3 table rows)
+
+enum { ST_OVER_SCALE = 1, ST_OVER_IMG = 2, ST_OVER_KEEP = 4, ST_DEGENERATE = 8 };
+
+struct LevelDesc {
+  int Hs, Ws, Hp, Wp, H2, W2, oh, ow;
+  float scale;
+  int off_px, off_p1, off_c2, off_out;  // prefix offsets (in pixels of that stage) over levels
+};
+
+struct LevelTable {
+  int n;
+  int tot_px, tot_p1, tot_c2, tot_out;
+  LevelDesc l[MAX_LEVELS];
+};
+
+struct PNetW {  // transposed to [cin][3][3][cout] so one tap's output-channel weights are contiguous
+  const float *w1, *b1, *a1, *w2, *b2, *a2, *w3, *b3, *a3, *w41, *b41, *w42, *b42;
+};
+
+struct Cand { float score, r0, r1, r2, r3; int cell; };
+struct Row { float x1, y1, x2, y2, score; int y, ey, x, ex; };  // stage-2 / stage-3 table row
+
+__device__ __forceinline__ int find_level(const LevelTable& t, int idx, int which) {
+  int l = 0;
+#pragma unroll 1
+  for (int i = 1; i < t.n; ++i) {
+    const int off = which == 0 ? t.l[i].off_px : which == 1 ? t.l[i].off_p1 : which == 2 ? t.l[i].off_c2 : t.l[i].off_out;
+    if (idx >= off) l = i;
+  }
+  return l;
+}
+
+// --------------------------------------------------------------------------------------------- K1
+// detect_face.py:71-72: imresample(imgs, (int(h*s+1), int(w*s+1))) then (x-127.5)*0.0078125.
+// interpolate(mode='area') == adaptive average pooling: bin [floor(i*H/oh), ceil((i+1)*H/oh)),
+// value = sum / kh / kw (two divisions, as ATen rounds).  Pixel sums of 8-bit data are exact in fp32.
+__global__ void pyramid_kernel(const uint8_t* __restrict__ frames, int H, int W, LevelTable t, float* __restrict__ lvl) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= t.tot_px) return;
+  const int img = blockIdx.y;
+  const int li = find_level(t, idx, 0);
+  const LevelDesc L = t.l[li];
+  const int p = idx - L.off_px, y = p / L.Ws, x = p - y * L.Ws;
+  const int h0 = (int)(((long long)y * H) / L.Hs), h1 = (int)((((long long)(y + 1)) * H + L.Hs - 1) / L.Hs);
+  const int w0 = (int)(((long long)x * W) / L.Ws), w1 = (int)((((long long)(x + 1)) * W + L.Ws - 1) / L.Ws);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  const uint8_t* base = frames + (size_t)img * H * W * 3;
+  for (int yy = h0; yy < h1; ++yy) {
+    const uint8_t* row = base + ((size_t)yy * W + w0) * 3;
+    for (int xx = 0; xx < w1 - w0; ++xx) {
+      s0 += (float)row[3 * xx];
+      s1 += (float)row[3 * xx + 1];
+      s2 += (float)row[3 * xx + 2];
+    }
+  }
+  const float kh = (float)(h1 - h0), kw = (float)(w1 - w0);
+  float* o = lvl + ((size_t)img * 3) * t.tot_px + L.off_px + p;
+  o[0] = ((s0 / kh) / kw - 127.5f) * 0.0078125f;
+  o[(size_t)t.tot_px] = ((s1 / kh) / kw - 127.5f) * 0.0078125f;
+  o[2 * (size_t)t.tot_px] = ((s2 / kh) / kw - 127.5f) * 0.0078125f;
+}
+
+// --------------------------------------------------------------------------------------------- K2
+// mtcnn.py:39-41: conv1 3->10 (3x3) + PReLU, then MaxPool2d(2,2,ceil_mode=True); one thread per
+// pooled pixel, all 10 channels in registers.
+__global__ void pnet_conv1_pool_kernel(const float* __restrict__ lvl, LevelTable t, PNetW w, float* __restrict__ p1) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= t.tot_p1) return;
+  const int img = blockIdx.y;
+  const int li = find_level(t, idx, 1);
+  const LevelDesc L = t.l[li];
+  const int p = idx - L.off_p1, py = p / L.Wp, px = p - py * L.Wp;
+  const int Hc = L.Hs - 2, Wc = L.Ws - 2;
+  float in[3][4][4];
+  const float* src = lvl + ((size_t)img * 3) * t.tot_px + L.off_px;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) {
+        const int yy = 2 * py + dy, xx = 2 * px + dx;
+        in[c][dy][dx] = (yy < L.Hs && xx < L.Ws) ? src[(size_t)c * t.tot_px + yy * L.Ws + xx] : 0.f;
+      }
+  float best[10];
+#pragma unroll
+  for (int co = 0; co < 10; ++co) best[co] = -INFINITY;
+#pragma unroll
+  for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+    for (int ox = 0; ox < 2; ++ox) {
+      if (2 * py + oy < Hc && 2 * px + ox < Wc) {
+        float acc[10];
+#pragma unroll
+        for (int co = 0; co < 10; ++co) acc[co] = w.b1[co];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const float v = in[c][oy + kh][ox + kw];
+              const float* ww = w.w1 + ((c * 3 + kh) * 3 + kw) * 10;
+#pragma unroll
+              for (int co = 0; co < 10; ++co) acc[co] = fmaf(v, ww[co], acc[co]);
+            }
+#pragma unroll
+        for (int co = 0; co < 10; ++co) {
+          const float a = acc[co] > 0.f ? acc[co] : acc[co] * w.a1[co];
+          best[co] = fmaxf(best[co], a);
+        }
+      }
+    }
+  float* o = p1 + ((size_t)img * 10) * t.tot_p1 + L.off_p1 + p;
+#pragma unroll
+  for (int co = 0; co < 10; ++co) o[(size_t)co * t.tot_p1] = best[co];
+}
+
+// mtcnn.py:42-43: conv2 10->16 (3x3) + PReLU
+__global__ void pnet_conv2_kernel(const float* __restrict__ p1, LevelTable t, PNetW w, float* __restrict__ c2) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= t.tot_c2) return;
+  const int img = blockIdx.y;
+  const int li = find_level(t, idx, 2);
+  const LevelDesc L = t.l[li];
+  const int p = idx - L.off_c2, y = p / L.W2, x = p - y * L.W2;
+  const float* src = p1 + ((size_t)img * 10) * t.tot_p1 + L.off_p1;
+  float acc[16];
+#pragma unroll
+  for (int co = 0; co < 16; ++co) acc[co] = w.b2[co];
+#pragma unroll 1
+  for (int c = 0; c < 10; ++c) {
+    const float* sc = src + (size_t)c * t.tot_p1 + y * L.Wp + x;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float v = sc[kh * L.Wp + kw];
+        const float* ww = w.w2 + ((c * 3 + kh) * 3 + kw) * 16;
+#pragma unroll
+        for (int co = 0; co < 16; ++co) acc[co] = fmaf(v, ww[co], acc[co]);
+      }
+  }
+  float* o = c2 + ((size_t)img * 16) * t.tot_c2 + L.off_c2 + p;
+#pragma unroll
+  for (int co = 0; co < 16; ++co) o[(size_t)co * t.tot_c2] = acc[co] > 0.f ? acc[co] : acc[co] * w.a2[co];
+}
+
+// mtcnn.py:44-49: conv3 16->32 + PReLU, conv4_1 (1x1 ->2) + softmax, conv4_2 (1x1 -> 4);
+// detect_face.py:209: mask = prob[:,1] >= thr, fused: survivors are appended to the
+// (level, frame) candidate list.  prob_dbg / reg_dbg (optional) receive the dense maps.
+__global__ void pnet_conv3_heads_kernel(const float* __restrict__ c2, LevelTable t, PNetW w, float thr, int B,
+                                        Cand* __restrict__ cand, int* __restrict__ cand_cnt, int* __restrict__ status,
+                                        float* __restrict__ prob_dbg, float* __restrict__ reg_dbg) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= t.tot_out) return;
+  const int img = blockIdx.y;
+  const int li = find_level(t, idx, 3);
+  const LevelDesc L = t.l[li];
+  const int p = idx - L.off_out, y = p / L.ow, x = p - y * L.ow;
+  const float* src = c2 + ((size_t)img * 16) * t.tot_c2 + L.off_c2;
+  float acc[32];
+#pragma unroll
+  for (int co = 0; co < 32; ++co) acc[co] = w.b3[co];
+#pragma unroll 1
+  for (int c = 0; c < 16; ++c) {
+    const float* sc = src + (size_t)c * t.tot_c2 + y * L.W2 + x;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float v = sc[kh * L.W2 + kw];
+        const float* ww = w.w3 + ((c * 3 + kh) * 3 + kw) * 32;
+#pragma unroll
+        for (int co = 0; co < 32; ++co) acc[co] = fmaf(v, ww[co], acc[co]);
+      }
+  }
+  float a0 = w.b41[0], a1 = w.b41[1], r0 = w.b42[0], r1 = w.b42[1], r2 = w.b42[2], r3 = w.b42[3];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const float v = acc[c] > 0.f ? acc[c] : acc[c] * w.a3[c];
+    a0 = fmaf(v, w.w41[c * 2 + 0], a0);
+    a1 = fmaf(v, w.w41[c * 2 + 1], a1);
+    r0 = fmaf(v, w.w42[c * 4 + 0], r0);
+    r1 = fmaf(v, w.w42[c * 4 + 1], r1);
+    r2 = fmaf(v, w.w42[c * 4 + 2], r2);
+    r3 = fmaf(v, w.w42[c * 4 + 3], r3);
+  }
+  const float m = fmaxf(a0, a1);
+  const float e0 = expf(a0 - m), e1 = expf(a1 - m);
+  const float prob = e1 / (e0 + e1);
+  if (prob_dbg) {
+    prob_dbg[(size_t)img * t.tot_out + idx] = prob;
+    float* rd = reg_dbg + ((size_t)img * 4) * t.tot_out + idx;
+    rd[0] = r0; rd[(size_t)t.tot_out] = r1; rd[2 * (size_t)t.tot_out] = r2; rd[3 * (size_t)t.tot_out] = r3;
+  }
+  if (prob >= thr) {
+    const int seg = li * B + img;
+    const int slot = atomicAdd(&cand_cnt[seg], 1);
+    if (slot < CAP_SCALE) {
+      Cand c;
+      c.score = prob; c.r0 = r0; c.r1 = r1; c.r2 = r2; c.r3 = r3; c.cell = p;
+      cand[(size_t)seg * CAP_SCALE + slot] = c;
+    } else {
+      atomicOr(status, ST_OVER_SCALE);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------- sort / NMS helpers
+__device__ __forceinline__ unsigned inv_score_bits(float s) { return 0xFFFFFFFFu - __float_as_uint(s); }  // s >= 0
+
+__device__ void block_bitonic_sort(unsigned long long* keys, int npad) {
+  for (int k = 2; k <= npad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const bool up = ((i & k) == 0);
+          const unsigned long long a = keys[i], b = keys[ixj];
+          if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int next_pow2(int n) {
+  int p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+// torchvision.ops.nms overlap (area without +1) or nms_numpy 'Min' overlap (areas with +1)
+template <bool MIN_MODE>
+__device__ __forceinline__ bool overlaps(const float4 a, float aa, const float4 b, float ab, float thr) {
+  const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y), xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
+  if (MIN_MODE) {
+    const float w = fmaxf(0.f, xx2 - xx1 + 1.f), h = fmaxf(0.f, yy2 - yy1 + 1.f);
+    const float inter = w * h;
+    return !(inter / fminf(aa, ab) <= thr);
+  } else {
+    const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+    const float inter = w * h;
+    return inter / (aa + ab - inter) > thr;
+  }
+}
+template <bool MIN_MODE>
+__device__ __forceinline__ float box_area(const float4 b) {
+  return MIN_MODE ? (b.z - b.x + 1.f) * (b.w - b.y + 1.f) : (b.z - b.x) * (b.w - b.y);
+}
+
+// Greedy NMS over n boxes already in visiting order.  getbox(rank) returns the box of the rank-th
+// candidate.  Kept ranks are appended to s_keep (LDS, capacity keep_cap); returns the kept count
+// (uniform).  s_kbox caches the kept boxes, s_cbox / s_alive hold the current chunk.
+template <bool MIN_MODE, typename GetBox>
+__device__ int block_greedy_nms(int n, float thr, GetBox getbox, int* s_keep, float4* s_kbox, int keep_cap,
+                                float4* s_cbox, int* s_alive, int* status) {
+  int nkeep = 0;
+  const int t = threadIdx.x, BS = blockDim.x;
+  for (int base = 0; base < n; base += BS) {
+    const int r = base + t;
+    const bool valid = r < n;
+    float4 box = valid ? getbox(r) : float4{0.f, 0.f, 0.f, 0.f};
+    const float area = box_area<MIN_MODE>(box);
+    bool alive = valid;
+    for (int k = 0; k < nkeep && alive; ++k) {
+      const float4 kb = s_kbox[k];
+      if (overlaps<MIN_MODE>(kb, box_area<MIN_MODE>(kb), box, area, thr)) alive = false;
+    }
+    s_cbox[t] = box;
+    s_alive[t] = alive ? 1 : 0;
+    __syncthreads();
+    const int lim = min(BS, n - base);
+    for (int c = 0; c < lim; ++c) {
+      if (s_alive[c]) {  // block-uniform
+        if (nkeep < keep_cap) {
+          if (t == c) { s_keep[nkeep] = r; s_kbox[nkeep] = box; }
+        } else if (t == 0) {
+          atomicOr(status, ST_OVER_KEEP);
+        }
+        if (nkeep < keep_cap) ++nkeep;
+        if (t > c && alive) {
+          const float4 cb = s_cbox[c];
+          if (overlaps<MIN_MODE>(cb, box_area<MIN_MODE>(cb), box, area, thr)) { alive = false; s_alive[t] = 0; }
+        }
+        __syncthreads();
+      }
+    }
+    __syncthreads();
+  }
+  return nkeep;
+}
+
+__device__ __forceinline__ float4 cell_box(int cell, int ow, float scale) {
+  // detect_face.py:214-216: stride 2, cellsize 12; fp32 division by the fp32-rounded scale
+  const int y = cell / ow, x = cell - y * ow;
+  const float fx = (float)x, fy = (float)y;
+  return float4{floorf((2.f * fx + 1.f) / scale), floorf((2.f * fy + 1.f) / scale),
+                floorf((2.f * fx + 12.f) / scale), floorf((2.f * fy + 12.f) / scale)};
+}
+
+// --------------------------------------------------------------------------------------------- K4a
+// detect_face.py:79: batched_nms(..., 0.5) within each (scale, image).  Visiting order = stable
+// score-descending over nonzero() order (y, x): key = (inverted score | cell | slot).
+__global__ void __launch_bounds__(256) nms_scale_kernel(const Cand* __restrict__ cand, const int* __restrict__ cand_cnt,
+                                                         LevelTable t, int B, float thr, Cand* __restrict__ keep,
+                                                         int* __restrict__ keep_cnt, int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);           // CAP_SCALE * 8
+  float4* s_kbox = reinterpret_cast<float4*>(smem + CAP_SCALE * 8);                  // KEEP * 16
+  int* s_keep = reinterpret_cast<int*>(smem + CAP_SCALE * 8 + KEEP * 16);            // KEEP * 4
+  float4* s_cbox = reinterpret_cast<float4*>(smem + CAP_SCALE * 8 + KEEP * 20);      // 256 * 16
+  int* s_alive = reinterpret_cast<int*>(smem + CAP_SCALE * 8 + KEEP * 20 + 256 * 16);
+  const int li = blockIdx.x, img = blockIdx.y, seg = li * B + img;
+  const int n = min(cand_cnt[seg], CAP_SCALE);
+  if (n == 0) {
+    if (threadIdx.x == 0) keep_cnt[seg] = 0;
+    return;
+  }
+  const Cand* c = cand + (size_t)seg * CAP_SCALE;
+  const int npad = next_pow2(n);
+  for (int i = threadIdx.x; i < npad; i += blockDim.x)
+    keys[i] = i < n ? ((unsigned long long)inv_score_bits(c[i].score) << 32) | ((unsigned long long)(unsigned)c[i].cell << 12) | (unsigned)i
+                    : ~0ull;
+  __syncthreads();
+  block_bitonic_sort(keys, npad);
+  const int ow = t.l[li].ow;
+  const float scale = t.l[li].scale;
+  auto getbox = [&](int r) { return cell_box(c[(int)(keys[r] & 0xFFF)].cell, ow, scale); };
+  const int nk = block_greedy_nms<false>(n, thr, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
+  Cand* o = keep + (size_t)seg * KEEP;
+  for (int k = threadIdx.x; k < nk; k += blockDim.x) o[k] = c[(int)(keys[s_keep[k]] & 0xFFF)];
+  if (threadIdx.x == 0) keep_cnt[seg] = nk;
+}
+
+// --------------------------------------------------------------------------------------------- K4b
+// detect_face.py:83-104: concatenate the per-scale survivors, batched_nms(..., 0.7) per image,
+// regress with (w,h) WITHOUT +1, rerec (square), pad (trunc + clamp).  Table order = visiting
+// order (score descending; ties: scale order, then within-scale order).
+__device__ __forceinline__ void rerec_pad(float& x1, float& y1, float& x2, float& y2, int W, int H, Row& r) {
+  const float h = y2 - y1, w = x2 - x1;
+  const float l = fmaxf(w, h);
+  x1 = x1 + w * 0.5f - l * 0.5f;
+  y1 = y1 + h * 0.5f - l * 0.5f;
+  x2 = x1 + l;
+  y2 = y1 + l;
+  int ix = (int)truncf(x1), iy = (int)truncf(y1), iex = (int)truncf(x2), iey = (int)truncf(y2);
+  if (ix < 1) ix = 1;
+  if (iy < 1) iy = 1;
+  if (iex > W) iex = W;
+  if (iey > H) iey = H;
+  r.x1 = x1; r.y1 = y1; r.x2 = x2; r.y2 = y2;
+  r.x = ix; r.y = iy; r.ex = iex; r.ey = iey;
+}
+
+__global__ void __launch_bounds__(256) nms_image_kernel(const Cand* __restrict__ keep1, const int* __restrict__ keep1_cnt,
+                                                         LevelTable t, int B, float thr, int W, int H,
+                                                         Row* __restrict__ rows, int* __restrict__ row_cnt,
+                                                         int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);           // CAP_IMG * 8
+  float4* s_kbox = reinterpret_cast<float4*>(smem + CAP_IMG * 8);
+  int* s_keep = reinterpret_cast<int*>(smem + CAP_IMG * 8 + KEEP * 16);
+  float4* s_cbox = reinterpret_cast<float4*>(smem + CAP_IMG * 8 + KEEP * 20);
+  int* s_alive = reinterpret_cast<int*>(smem + CAP_IMG * 8 + KEEP * 20 + 256 * 16);
+  __shared__ int s_off[MAX_LEVELS + 1];
+  const int img = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int l = 0; l < t.n; ++l) { s_off[l] = acc; acc += keep1_cnt[l * B + img]; }
+    s_off[t.n] = acc;
+    if (acc > CAP_IMG) atomicOr(status, ST_OVER_IMG);
+  }
+  __syncthreads();
+  const int n = min(s_off[t.n], CAP_IMG);
+  if (n == 0) {
+    if (threadIdx.x == 0) row_cnt[img] = 0;
+    return;
+  }
+  auto locate = [&](int g, int& l) -> const Cand* {  // gathered index -> record
+    l = 0;
+    for (int i = 1; i < t.n; ++i)
+      if (g >= s_off[i]) l = i;
+    return keep1 + (size_t)(l * B + img) * KEEP + (g - s_off[l]);
+  };
+  const int npad = next_pow2(n);
+  for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+    if (i < n) {
+      int l;
+      const Cand* c = locate(i, l);
+      keys[i] = ((unsigned long long)inv_score_bits(c->score) << 32) | (unsigned)i;
+    } else {
+      keys[i] = ~0ull;
+    }
+  }
+  __syncthreads();
+  block_bitonic_sort(keys, npad);
+  auto getbox = [&](int r) {
+    int l;
+    const Cand* c = locate((int)(keys[r] & 0xFFFFFFFFu), l);
+    return cell_box(c->cell, t.l[l].ow, t.l[l].scale);
+  };
+  const int nk = block_greedy_nms<false>(n, thr, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
+  for (int k = threadIdx.x; k < nk; k += blockDim.x) {
+    int l;
+    const Cand* c = locate((int)(keys[s_keep[k]] & 0xFFFFFFFFu), l);
+    const float4 b = s_kbox[k];
+    const float regw = b.z - b.x, regh = b.w - b.y;
+    float x1 = b.x + c->r0 * regw, y1 = b.y + c->r1 * regh, x2 = b.z + c->r2 * regw, y2 = b.w + c->r3 * regh;
+    Row r;
+    rerec_pad(x1, y1, x2, y2, W, H, r);
+    r.score = c->score;
+    rows[(size_t)img * KEEP + k] = r;
+  }
+  if (threadIdx.x == 0) row_cnt[img] = nk;
+}
+
+// --------------------------------------------------------------------------------------------- K5
+// detect_face.py:109-114 / 138-143: imgs[i, :, y-1:ey, x-1:ex] -> imresample(S,S) -> normalise.
+// One workgroup per candidate; output NCHW fp32 (3,S,S).  Degenerate rectangles (the reference
+// silently drops them from im_data, which would desynchronise its tables) are flagged and zeroed.
+__global__ void __launch_bounds__(256) crop_resize_kernel(const uint8_t* __restrict__ frames, int H, int W,
+                                                           const Row* __restrict__ rows, const int* __restrict__ row_cnt,
+                                                           int S, float* __restrict__ out, int* __restrict__ status) {
+  const int k = blockIdx.x, img = blockIdx.y;
+  if (k >= row_cnt[img]) return;
+  const Row r = rows[(size_t)img * KEEP + k];
+  const int y0 = r.y - 1, x0 = r.x - 1, ch = r.ey - y0, cw = r.ex - x0;
+  float* o = out + ((size_t)img * KEEP + k) * 3 * S * S;
+  if (ch <= 0 || cw <= 0) {
+    for (int i = threadIdx.x; i < 3 * S * S; i += blockDim.x) o[i] = 0.f;
+    if (threadIdx.x == 0) atomicOr(status, ST_DEGENERATE);
+    return;
+  }
+  const uint8_t* base = frames + ((size_t)img * H + y0) * (size_t)W * 3 + (size_t)x0 * 3;
+  for (int i = threadIdx.x; i < S * S; i += blockDim.x) {
+    const int oy = i / S, ox = i - oy * S;
+    const int h0 = (oy * ch) / S, h1 = ((oy + 1) * ch + S - 1) / S;
+    const int w0 = (ox * cw) / S, w1 = ((ox + 1) * cw + S - 1) / S;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int yy = h0; yy < h1; ++yy) {
+      const uint8_t* row = base + ((size_t)yy * W + w0) * 3;
+      for (int xx = 0; xx < w1 - w0; ++xx) {
+        s0 += (float)row[3 * xx]; s1 += (float)row[3 * xx + 1]; s2 += (float)row[3 * xx + 2];
+      }
+    }
+    const float kh = (float)(h1 - h0), kw = (float)(w1 - w0);
+    o[i] = ((s0 / kh) / kw - 127.5f) * 0.0078125f;
+    o[S * S + i] = ((s1 / kh) / kw - 127.5f) * 0.0078125f;
+    o[2 * S * S + i] = ((s2 / kh) / kw - 127.5f) * 0.0078125f;
+  }
+}
+
+// --------------------------------------------------------------------------------------------- K6 building blocks
+// Direct convolution / pooling / dense layers over activations resident in LDS (CHW fp32),
+// weights in their PyTorch layout read through L1/L2 (shared by every workgroup).
+__device__ __forceinline__ float prelu(float v, float a) { return v > 0.f ? v : v * a; }
+
+template <int CIN, int KS>
+__device__ void lds_conv_prelu(const float* __restrict__ in, int Hi, int Wi, float* __restrict__ out, int cout,
+                               const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ a) {
+  const int Ho = Hi - KS + 1, Wo = Wi - KS + 1, n = cout * Ho * Wo;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int co = i / (Ho * Wo), p = i - co * (Ho * Wo), y = p / Wo, x = p - y * Wo;
+    float acc = b[co];
+    const float* wc = w + (size_t)co * CIN * KS * KS;
+#pragma unroll 1
+    for (int c = 0; c < CIN; ++c) {
+      const float* ic = in + c * Hi * Wi + y * Wi + x;
+#pragma unroll
+      for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) acc = fmaf(ic[kh * Wi + kw], wc[(c * KS + kh) * KS + kw], acc);
+    }
+    out[i] = prelu(acc, a[co]);
+  }
+}
+
+// conv + PReLU + MaxPool(PK, 2, ceil_mode=True) fused (recomputes the conv under overlapping windows):
+// used where the un-pooled map would not fit LDS.
+template <int CIN, int KS, int PK>
+__device__ void lds_conv_prelu_pool(const float* __restrict__ in, int Hi, int Wi, float* __restrict__ out, int cout,
+                                    const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ a) {
+  const int Hc = Hi - KS + 1, Wc = Wi - KS + 1;
+  const int Hp = (Hc - PK + 1) / 2 + 1, Wp = (Wc - PK + 1) / 2 + 1;  // ceil((Hc-PK)/2)+1
+  const int n = cout * Hp * Wp;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int co = i / (Hp * Wp), p = i - co * (Hp * Wp), py = p / Wp, px = p - py * Wp;
+    const float* wc = w + (size_t)co * CIN * KS * KS;
+    float best = -INFINITY;
+    for (int oy = 0; oy < PK; ++oy)
+      for (int ox = 0; ox < PK; ++ox) {
+        const int y = 2 * py + oy, x = 2 * px + ox;
+        if (y < Hc && x < Wc) {
+          float acc = b[co];
+#pragma unroll 1
+          for (int c = 0; c < CIN; ++c) {
+            const float* ic = in + c * Hi * Wi + y * Wi + x;
+#pragma unroll
+            for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+              for (int kw = 0; kw < KS; ++kw) acc = fmaf(ic[kh * Wi + kw], wc[(c * KS + kh) * KS + kw], acc);
+          }
+          best = fmaxf(best, prelu(acc, a[co]));
+        }
+      }
+    out[i] = best;
+  }
+}
+
+template <int PK>
+__device__ void lds_maxpool_ceil(const float* __restrict__ in, int C, int Hi, int Wi, float* __restrict__ out) {
+  const int Hp = (Hi - PK + 1) / 2 + 1, Wp = (Wi - PK + 1) / 2 + 1;
+  for (int i = threadIdx.x; i < C * Hp * Wp; i += blockDim.x) {
+    const int c = i / (Hp * Wp), p = i - c * (Hp * Wp), py = p / Wp, px = p - py * Wp;
+    float best = -INFINITY;
+    for (int oy = 0; oy < PK; ++oy)
+      for (int ox = 0; ox < PK; ++ox) {
+        const int y = 2 * py + oy, x = 2 * px + ox;
+        if (y < Hi && x < Wi) best = fmaxf(best, in[c * Hi * Wi + y * Wi + x]);
+      }
+    out[i] = best;
+  }
+}
+
+// dense layer on x.permute(0,3,2,1) flattened (mtcnn.py:93-94,150-151): feature f = (w*H + h)*C + c
+__device__ void lds_dense_permuted_prelu(const float* __restrict__ in, int C, int Hh, int Ww, float* __restrict__ out,
+                                         int nout, const float* __restrict__ w, const float* __restrict__ b,
+                                         const float* __restrict__ a) {
+  const int nin = C * Hh * Ww;
+  for (int o = threadIdx.x; o < nout; o += blockDim.x) {
+    float acc = b[o];
+    const float* wr = w + (size_t)o * nin;
+    for (int f = 0; f < nin; ++f) {
+      const int c = f % C, hw = f / C, h = hw % Hh, ww_ = hw / Hh;
+      acc = fmaf(in[c * Hh * Ww + h * Ww + ww_], wr[f], acc);
+    }
+    out[o] = prelu(acc, a[o]);
+  }
+}
+
+struct RNetW {
+  const float *c1w, *c1b, *a1, *c2w, *c2b, *a2, *c3w, *c3b, *a3, *d4w, *d4b, *a4, *d51w, *d51b, *d52w, *d52b;
+};
+struct ONetW {
+  const float *c1w, *c1b, *a1, *c2w, *c2b, *a2, *c3w, *c3b, *a3, *c4w, *c4b, *a4, *d5w, *d5b, *a5, *d61w, *d61b, *d62w,
+      *d62b, *d63w, *d63b;
+};
+
+// mtcnn.py:84-99.  out: [score, reg0..3] per candidate.
+__global__ void __launch_bounds__(256) rnet_kernel(const float* __restrict__ crops, const int* __restrict__ row_cnt,
+                                                    RNetW w, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int k = blockIdx.x, img = blockIdx.y;
+  if (k >= row_cnt[img]) return;
+  float* A = reinterpret_cast<float*>(smem);            // 28*22*22 = 13552 floats
+  float* Bf = A + 13552;                                // 28*11*11 = 3388 floats (>= 3*24*24 = 1728)
+  const float* src = crops + ((size_t)img * KEEP + k) * 3 * 24 * 24;
+  for (int i = threadIdx.x; i < 1728; i += blockDim.x) Bf[i] = src[i];
+  __syncthreads();
+  lds_conv_prelu<3, 3>(Bf, 24, 24, A, 28, w.c1w, w.c1b, w.a1);            // 28 x 22 x 22
+  __syncthreads();
+  lds_maxpool_ceil<3>(A, 28, 22, 22, Bf);                                  // 28 x 11 x 11
+  __syncthreads();
+  lds_conv_prelu<28, 3>(Bf, 11, 11, A, 48, w.c2w, w.c2b, w.a2);            // 48 x 9 x 9
+  __syncthreads();
+  lds_maxpool_ceil<3>(A, 48, 9, 9, Bf);                                    // 48 x 4 x 4
+  __syncthreads();
+  lds_conv_prelu<48, 2>(Bf, 4, 4, A, 64, w.c3w, w.c3b, w.a3);              // 64 x 3 x 3
+  __syncthreads();
+  lds_dense_permuted_prelu(A, 64, 3, 3, Bf, 128, w.d4w, w.d4b, w.a4);
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int o = threadIdx.x;
+    const float* wr = o < 2 ? w.d51w + o * 128 : w.d52w + (o - 2) * 128;
+    float acc = o < 2 ? w.d51b[o] : w.d52b[o - 2];
+    for (int f = 0; f < 128; ++f) acc = fmaf(Bf[f], wr[f], acc);
+    A[o] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float m = fmaxf(A[0], A[1]);
+    const float e0 = expf(A[0] - m), e1 = expf(A[1] - m);
+    float* o = out + ((size_t)img * KEEP + k) * 5;
+    o[0] = e1 / (e0 + e1);
+    o[1] = A[2]; o[2] = A[3]; o[3] = A[4]; o[4] = A[5];
+  }
+}
+
+// mtcnn.py:138-157.  out: [score, reg0..3, lm0..9] per candidate.
+__global__ void __launch_bounds__(512) onet_kernel(const float* __restrict__ crops, const int* __restrict__ row_cnt,
+                                                    ONetW w, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int k = blockIdx.x, img = blockIdx.y;
+  if (k >= row_cnt[img]) return;
+  float* X = reinterpret_cast<float*>(smem);   // 32*23*23 = 16928 floats
+  float* Y = X + 16928;                        // 32*21*21 = 14112 floats (>= 3*48*48 = 6912)
+  float* Z = Y + 14112;                        // 64*10*10 = 6400 floats
+  const float* src = crops + ((size_t)img * KEEP + k) * 3 * 48 * 48;
+  for (int i = threadIdx.x; i < 6912; i += blockDim.x) Y[i] = src[i];
+  __syncthreads();
+  lds_conv_prelu_pool<3, 3, 3>(Y, 48, 48, X, 32, w.c1w, w.c1b, w.a1);     // conv 46x46 -> pool 23x23
+  __syncthreads();
+  for (int half = 0; half < 2; ++half) {  // conv2 in two 32-channel halves: the full 64x21x21 map would not fit LDS
+    lds_conv_prelu<32, 3>(X, 23, 23, Y, 32, w.c2w + (size_t)half * 32 * 32 * 9, w.c2b + half * 32, w.a2 + half * 32);
+    __syncthreads();
+    lds_maxpool_ceil<3>(Y, 32, 21, 21, Z + half * 32 * 100);              // -> 64 x 10 x 10
+    __syncthreads();
+  }
+  lds_conv_prelu<64, 3>(Z, 10, 10, Y, 64, w.c3w, w.c3b, w.a3);            // 64 x 8 x 8
+  __syncthreads();
+  lds_maxpool_ceil<2>(Y, 64, 8, 8, X);                                     // 64 x 4 x 4
+  __syncthreads();
+  lds_conv_prelu<64, 2>(X, 4, 4, Y, 128, w.c4w, w.c4b, w.a4);             // 128 x 3 x 3
+  __syncthreads();
+  lds_dense_permuted_prelu(Y, 128, 3, 3, X, 256, w.d5w, w.d5b, w.a5);
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int o = threadIdx.x;
+    const float* wr = o < 2 ? w.d61w + o * 256 : o < 6 ? w.d62w + (o - 2) * 256 : w.d63w + (o - 6) * 256;
+    float acc = o < 2 ? w.d61b[o] : o < 6 ? w.d62b[o - 2] : w.d63b[o - 6];
+    for (int f = 0; f < 256; ++f) acc = fmaf(X[f], wr[f], acc);
+    Y[o] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float m = fmaxf(Y[0], Y[1]);
+    const float e0 = expf(Y[0] - m), e1 = expf(Y[1] - m);
+    float* o = out + ((size_t)img * KEEP + k) * 15;
+    o[0] = e1 / (e0 + e1);
+    for (int i = 0; i < 14; ++i) o[1 + i] = Y[2 + i];
+  }
+}
+
+// --------------------------------------------------------------------------------------------- stage-2 post
+// detect_face.py:119-131: keep score > thr, batched_nms(0.7) per image, bbreg (w,h WITH +1), rerec;
+// then pad for stage 3 (136).  Visiting order: score descending, ties by stage-1 table order.
+__global__ void __launch_bounds__(256) stage2_post_kernel(const Row* __restrict__ rows, const int* __restrict__ row_cnt,
+                                                           const float* __restrict__ rout, float thr_score, float thr_nms,
+                                                           int W, int H, Row* __restrict__ rows3, int* __restrict__ row3_cnt,
+                                                           int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // KEEP * 8
+  float4* s_kbox = reinterpret_cast<float4*>(smem + KEEP * 8);
+  int* s_keep = reinterpret_cast<int*>(smem + KEEP * 8 + KEEP * 16);
+  float4* s_cbox = reinterpret_cast<float4*>(smem + KEEP * 28);
+  int* s_alive = reinterpret_cast<int*>(smem + KEEP * 28 + 256 * 16);
+  __shared__ int s_n;
+  const int img = blockIdx.x;
+  const int n0 = row_cnt[img];
+  const Row* r = rows + (size_t)img * KEEP;
+  const float* ro = rout + (size_t)img * KEEP * 5;
+  const int npad = next_pow2(max(n0, 1));
+  for (int i = threadIdx.x; i < npad; i += blockDim.x)
+    keys[i] = (i < n0 && ro[i * 5] > thr_score) ? ((unsigned long long)inv_score_bits(ro[i * 5]) << 32) | (unsigned)i : ~0ull;
+  __syncthreads();
+  block_bitonic_sort(keys, npad);
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n0;  // first padded key
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] == ~0ull) hi = mid; else lo = mid + 1; }
+    s_n = lo;
+  }
+  __syncthreads();
+  const int n = s_n;
+  auto getbox = [&](int q) { const Row& b = r[(int)(keys[q] & 0xFFFFFFFFu)]; return float4{b.x1, b.y1, b.x2, b.y2}; };
+  const int nk = block_greedy_nms<false>(n, thr_nms, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
+  for (int k = threadIdx.x; k < nk; k += blockDim.x) {
+    const int src = (int)(keys[s_keep[k]] & 0xFFFFFFFFu);
+    const float4 b = s_kbox[k];
+    const float* mv = ro + src * 5 + 1;
+    const float w = b.z - b.x + 1.f, h = b.w - b.y + 1.f;
+    float x1 = b.x + mv[0] * w, y1 = b.y + mv[1] * h, x2 = b.z + mv[2] * w, y2 = b.w + mv[3] * h;
+    Row o;
+    rerec_pad(x1, y1, x2, y2, W, H, o);
+    o.score = ro[src * 5];
+    rows3[(size_t)img * KEEP + k] = o;
+  }
+  if (threadIdx.x == 0) row3_cnt[img] = nk;
+}
+
+// --------------------------------------------------------------------------------------------- K7
+// detect_face.py:148-169: keep score > thr, landmarks, bbreg, nms_numpy(0.7, 'Min') per image
+// (visit from the highest score; equal scores -- softmax saturates to exactly 1.0f on clear faces --
+// are visited in table order: the reference leaves tie order to np.argsort's unstable default
+// sort, which is implementation defined; the oracle pins the same rule), then mtcnn.py:334-340: order by box area
+// descending (argsort ascending, reversed).  fin: [x1,y1,x2,y2,score, 10 landmark coords] rows.
+__global__ void __launch_bounds__(256) stage3_post_kernel(const Row* __restrict__ rows3, const int* __restrict__ row3_cnt,
+                                                           const float* __restrict__ oout, float thr_score, float thr_nms,
+                                                           int select_largest, float* __restrict__ fin,
+                                                           int* __restrict__ fin_cnt, int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+  float4* s_kbox = reinterpret_cast<float4*>(smem + KEEP * 8);
+  int* s_keep = reinterpret_cast<int*>(smem + KEEP * 8 + KEEP * 16);
+  float4* s_cbox = reinterpret_cast<float4*>(smem + KEEP * 28);
+  int* s_alive = reinterpret_cast<int*>(smem + KEEP * 28 + 256 * 16);
+  float4* s_reg = reinterpret_cast<float4*>(smem + KEEP * 28 + 256 * 20);  // KEEP * 16: boxes after bbreg
+  __shared__ int s_n;
+  const int img = blockIdx.x;
+  const int n0 = row3_cnt[img];
+  const Row* r = rows3 + (size_t)img * KEEP;
+  const float* oo = oout + (size_t)img * KEEP * 15;
+  for (int i = threadIdx.x; i < n0; i += blockDim.x) {  // bbreg of every row (w,h WITH +1)
+    const Row& b = r[i];
+    const float* mv = oo + i * 15 + 1;
+    const float w = b.x2 - b.x1 + 1.f, h = b.y2 - b.y1 + 1.f;
+    s_reg[i] = float4{b.x1 + mv[0] * w, b.y1 + mv[1] * h, b.x2 + mv[2] * w, b.y2 + mv[3] * h};
+  }
+  const int npad = next_pow2(max(n0, 1));
+  for (int i = threadIdx.x; i < npad; i += blockDim.x)  // ties: earlier row first (see header note on ties)
+    keys[i] = (i < n0 && oo[i * 15] > thr_score) ? ((unsigned long long)inv_score_bits(oo[i * 15]) << 32) | (unsigned)i : ~0ull;
+  __syncthreads();
+  block_bitonic_sort(keys, npad);
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n0;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] == ~0ull) hi = mid; else lo = mid + 1; }
+    s_n = lo;
+  }
+  __syncthreads();
+  const int n = s_n;
+  auto srcof = [&](int q) { return (int)(keys[q] & 0xFFFFFFFFu); };
+  auto getbox = [&](int q) { return s_reg[srcof(q)]; };
+  const int nk = block_greedy_nms<true>(n, thr_nms, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
+  __syncthreads();
+  // final order: area descending (argsort ascending reversed: ties -> later pick first)
+  // the score-sorted keys are dead after this: resolve kept ranks to source rows, then reuse `keys`
+  for (int k = threadIdx.x; k < nk; k += blockDim.x) s_keep[k] = srcof(s_keep[k]);
+  __syncthreads();
+  const int kpad = next_pow2(max(nk, 1));
+  for (int k = threadIdx.x; k < kpad; k += blockDim.x) {
+    if (k < nk) {
+      const float4 b = s_kbox[k];
+      const float area = (b.z - b.x) * (b.w - b.y);
+      // areas may be negative in degenerate cases: map float to an order-preserving unsigned
+      unsigned u = __float_as_uint(area);
+      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      keys[k] = select_largest ? ((unsigned long long)(0xFFFFFFFFu - u) << 32) | (unsigned)(0x7FFFFFFF - k)
+                               : (unsigned long long)k;
+    } else {
+      keys[k] = ~0ull;
+    }
+  }
+  __syncthreads();
+  block_bitonic_sort(keys, kpad);
+  float* fo = fin + (size_t)img * KEEP * 15;
+  for (int q = threadIdx.x; q < nk; q += blockDim.x) {
+    const int k = select_largest ? 0x7FFFFFFF - (int)(keys[q] & 0xFFFFFFFFu) : (int)keys[q];
+    const int src = s_keep[k];
+    const Row& b = r[src];
+    const float4 bb = s_kbox[k];
+    float* o = fo + q * 15;
+    o[0] = bb.x; o[1] = bb.y; o[2] = bb.z; o[3] = bb.w; o[4] = oo[src * 15];
+    // detect_face.py:159-163 (boxes BEFORE bbreg): px = w_i * p + x1 - 1
+    const float w_i = b.x2 - b.x1 + 1.f, h_i = b.y2 - b.y1 + 1.f;
+    const float* lm = oo + src * 15 + 5;
+    for (int j = 0; j < 5; ++j) {
+      o[5 + 2 * j] = w_i * lm[j] + b.x1 - 1.f;
+      o[6 + 2 * j] = h_i * lm[5 + j] + b.y1 - 1.f;
+    }
+  }
+  if (threadIdx.x == 0) fin_cnt[img] = nk;
+}
+
+// =============================================================================================
+// host side
+struct Mtcnn : HandleBase {
+  vnf_mtcnn_cfg cfg;
+  PNetW pw; RNetW rw; ONetW ow;
+  LevelTable cap_table;  // geometry at (max_height, max_width): sizes the buffers
+  float *lvl = nullptr, *p1 = nullptr, *c2 = nullptr;
+  Cand *cand = nullptr, *keep1 = nullptr;
+  int *cand_cnt = nullptr, *keep1_cnt = nullptr, *row_cnt = nullptr, *row3_cnt = nullptr, *fin_cnt = nullptr, *status = nullptr;
+  Row *rows = nullptr, *rows3 = nullptr;
+  float *crops = nullptr, *rout = nullptr, *oout = nullptr, *fin = nullptr;
+  float *prob_dbg = nullptr, *reg_dbg = nullptr;
+  size_t cap_px = 0, cap_p1 = 0, cap_c2 = 0, cap_out = 0;
+  std::vector<float> h_fin;
+  std::vector<int> h_cnt;
+  LevelTable last_table;
+};
+
+static LevelTable make_levels(int h, int w, int minsize, double factor) {
+  // detect_face.py:50-60,71 in python-double arithmetic
+  LevelTable t;
+  memset(&t, 0, sizeof(t));
+  const double m = 12.0 / minsize;
+  double minl = std::min(h, w) * m, scale = m;
+  int opx = 0, op1 = 0, oc2 = 0, oout = 0;
+  while (minl >= 12 && t.n < MAX_LEVELS) {
+    LevelDesc& L = t.l[t.n];
+    L.Hs = (int)(h * scale + 1);
+    L.Ws = (int)(w * scale + 1);
+    L.Hp = (L.Hs - 2 + 1) / 2;  // ceil((Hs-2)/2)
+    L.Wp = (L.Ws - 2 + 1) / 2;
+    L.H2 = L.Hp - 2; L.W2 = L.Wp - 2;
+    L.oh = L.H2 - 2; L.ow = L.W2 - 2;
+    L.scale = (float)scale;
+    L.off_px = opx; L.off_p1 = op1; L.off_c2 = oc2; L.off_out = oout;
+    opx += L.Hs * L.Ws; op1 += L.Hp * L.Wp; oc2 += L.H2 * L.W2; oout += L.oh * L.ow;
+    ++t.n;
+    scale = scale * factor;
+    minl = minl * factor;
+  }
+  t.tot_px = opx; t.tot_p1 = op1; t.tot_c2 = oc2; t.tot_out = oout;
+  return t;
+}
+
+static const float* up_transposed(Mtcnn& m, const float* w, int cout, int cin, int k) {
+  // [cout][cin][k][k] -> [cin][k][k][cout]
+  std::vector<float> t((size_t)cout * cin * k * k);
+  for (int co = 0; co < cout; ++co)
+    for (int c = 0; c < cin; ++c)
+      for (int i = 0; i < k * k; ++i) t[((size_t)c * k * k + i) * cout + co] = w[((size_t)co * cin + c) * k * k + i];
+  return (const float*)m.upload(t.data(), t.size() * 4);
+}
+
+#define GETW(dst, wmref, name, numel)                                                        \
+  const float* dst = (wmref).get(name, numel);                                               \
+  if (!dst) { delete m; return fail(VNF_E_MISSING, std::string("mtcnn: missing weight ") + (wmref).missing); }
+#define UP(ptr, numel) (const float*)m->upload(ptr, (size_t)(numel) * 4)
+
+}  // namespace vnf
+using namespace vnf;
+
+extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const vnf_tensor_desc* rnet, int n_rnet,
+                                const vnf_tensor_desc* onet, int n_onet, const vnf_mtcnn_cfg* cfg, vnf_handle* out) {
+  try {
+    if (!pnet || !rnet || !onet || !cfg || !out) return fail(VNF_E_INVALID, "vnf_mtcnn_create: bad argument");
+    if (cfg->min_face_size < 1 || cfg->max_batch < 1 || cfg->max_height < 12 || cfg->max_width < 12 ||
+        !(cfg->factor > 0.f && cfg->factor < 1.f))
+      return fail(VNF_E_INVALID, "vnf_mtcnn_create: bad configuration");
+    *out = nullptr;
+    Mtcnn* m = new Mtcnn();
+    m->kind = 3;
+    m->cfg = *cfg;
+    (void)hipGetDevice(&m->device);
+    WeightMap wp(pnet, n_pnet), wr(rnet, n_rnet), wo(onet, n_onet);
+    {
+      GETW(c1, wp, "conv1.weight", 270) GETW(b1, wp, "conv1.bias", 10) GETW(a1, wp, "prelu1.weight", 10)
+      GETW(c2, wp, "conv2.weight", 1440) GETW(b2, wp, "conv2.bias", 16) GETW(a2, wp, "prelu2.weight", 16)
+      GETW(c3, wp, "conv3.weight", 4608) GETW(b3, wp, "conv3.bias", 32) GETW(a3, wp, "prelu3.weight", 32)
+      GETW(c41, wp, "conv4_1.weight", 64) GETW(b41, wp, "conv4_1.bias", 2)
+      GETW(c42, wp, "conv4_2.weight", 128) GETW(b42, wp, "conv4_2.bias", 4)
+      m->pw.w1 = up_transposed(*m, c1, 10, 3, 3); m->pw.b1 = UP(b1, 10); m->pw.a1 = UP(a1, 10);
+      m->pw.w2 = up_transposed(*m, c2, 16, 10, 3); m->pw.b2 = UP(b2, 16); m->pw.a2 = UP(a2, 16);
+      m->pw.w3 = up_transposed(*m, c3, 32, 16, 3); m->pw.b3 = UP(b3, 32); m->pw.a3 = UP(a3, 32);
+      m->pw.w41 = up_transposed(*m, c41, 2, 32, 1); m->pw.b41 = UP(b41, 2);
+      m->pw.w42 = up_transposed(*m, c42, 4, 32, 1); m->pw.b42 = UP(b42, 4);
+    }
+    {
+      GETW(c1, wr, "conv1.weight", 756) GETW(b1, wr, "conv1.bias", 28) GETW(a1, wr, "prelu1.weight", 28)
+      GETW(c2, wr, "conv2.weight", 12096) GETW(b2, wr, "conv2.bias", 48) GETW(a2, wr, "prelu2.weight", 48)
+      GETW(c3, wr, "conv3.weight", 12288) GETW(b3, wr, "conv3.bias", 64) GETW(a3, wr, "prelu3.weight", 64)
+      GETW(d4, wr, "dense4.weight", 73728) GETW(d4b, wr, "dense4.bias", 128) GETW(a4, wr, "prelu4.weight", 128)
+      GETW(d51, wr, "dense5_1.weight", 256) GETW(d51b, wr, "dense5_1.bias", 2)
+      GETW(d52, wr, "dense5_2.weight", 512) GETW(d52b, wr, "dense5_2.bias", 4)
+      m->rw = RNetW{UP(c1, 756), UP(b1, 28), UP(a1, 28), UP(c2, 12096), UP(b2, 48), UP(a2, 48), UP(c3, 12288), UP(b3, 64),
+                    UP(a3, 64), UP(d4, 73728), UP(d4b, 128), UP(a4, 128), UP(d51, 256), UP(d51b, 2), UP(d52, 512), UP(d52b, 4)};
+    }
+    {
+      GETW(c1, wo, "conv1.weight", 864) GETW(b1, wo, "conv1.bias", 32) GETW(a1, wo, "prelu1.weight", 32)
+      GETW(c2, wo, "conv2.weight", 18432) GETW(b2, wo, "conv2.bias", 64) GETW(a2, wo, "prelu2.weight", 64)
+      GETW(c3, wo, "conv3.weight", 36864) GETW(b3, wo, "conv3.bias", 64) GETW(a3, wo, "prelu3.weight", 64)
+      GETW(c4, wo, "conv4.weight", 32768) GETW(b4, wo, "conv4.bias", 128) GETW(a4, wo, "prelu4.weight", 128)
+      GETW(d5, wo, "dense5.weight", 294912) GETW(d5b, wo, "dense5.bias", 256) GETW(a5, wo, "prelu5.weight", 256)
+      GETW(d61, wo, "dense6_1.weight", 512) GETW(d61b, wo, "dense6_1.bias", 2)
+      GETW(d62, wo, "dense6_2.weight", 1024) GETW(d62b, wo, "dense6_2.bias", 4)
+      GETW(d63, wo, "dense6_3.weight", 2560) GETW(d63b, wo, "dense6_3.bias", 10)
+      m->ow = ONetW{UP(c1, 864), UP(b1, 32), UP(a1, 32), UP(c2, 18432), UP(b2, 64), UP(a2, 64), UP(c3, 36864), UP(b3, 64),
+                    UP(a3, 64), UP(c4, 32768), UP(b4, 128), UP(a4, 128), UP(d5, 294912), UP(d5b, 256), UP(a5, 256),
+                    UP(d61, 512), UP(d61b, 2), UP(d62, 1024), UP(d62b, 4), UP(d63, 2560), UP(d63b, 10)};
+    }
+    const int B = cfg->max_batch;
+    m->cap_table = make_levels(cfg->max_height, cfg->max_width, cfg->min_face_size, (double)cfg->factor);
+    // other aspect ratios up to the same bounds can need slightly more: 10 % head-room
+    m->cap_px = (size_t)(m->cap_table.tot_px * 1.1) + 4096; m->cap_p1 = (size_t)(m->cap_table.tot_p1 * 1.1) + 4096;
+    m->cap_c2 = (size_t)(m->cap_table.tot_c2 * 1.1) + 4096; m->cap_out = (size_t)(m->cap_table.tot_out * 1.1) + 4096;
+    m->lvl = (float*)m->dalloc(m->cap_px * 3 * B * 4);
+    m->p1 = (float*)m->dalloc(m->cap_p1 * 10 * B * 4);
+    m->c2 = (float*)m->dalloc(m->cap_c2 * 16 * B * 4);
+    const size_t nseg = (size_t)MAX_LEVELS * B;
+    m->cand = (Cand*)m->dalloc(nseg * CAP_SCALE * sizeof(Cand));
+    m->keep1 = (Cand*)m->dalloc(nseg * KEEP * sizeof(Cand));
+    m->cand_cnt = (int*)m->dalloc((nseg * 2 + (size_t)B * 3 + 16) * 4);
+    m->keep1_cnt = m->cand_cnt + nseg;
+    m->row_cnt = m->keep1_cnt + nseg;
+    m->row3_cnt = m->row_cnt + B;
+    m->fin_cnt = m->row3_cnt + B;
+    m->status = m->fin_cnt + B;
+    m->rows = (Row*)m->dalloc((size_t)B * KEEP * sizeof(Row));
+    m->rows3 = (Row*)m->dalloc((size_t)B * KEEP * sizeof(Row));
+    m->crops = (float*)m->dalloc((size_t)B * KEEP * 3 * 48 * 48 * 4);
+    m->rout = (float*)m->dalloc((size_t)B * KEEP * 5 * 4);
+    m->oout = (float*)m->dalloc((size_t)B * KEEP * 15 * 4);
+    m->fin = (float*)m->dalloc((size_t)B * KEEP * 15 * 4);
+    if (!m->lvl || !m->p1 || !m->c2 || !m->cand || !m->keep1 || !m->cand_cnt || !m->rows || !m->rows3 || !m->crops ||
+        !m->rout || !m->oout || !m->fin || !m->pw.w1 || !m->ow.d63b) {
+      delete m;
+      return VNF_E_HIP;
+    }
+    // Dynamic LDS above 64 KiB: opt in with the exact sizes (gfx950 has 160 KiB per workgroup).
+    // The attribute call is advisory on some ROCm builds; launch errors are checked at run time.
+    {
+      int lds_max = 0;
+      VNF_HIP(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, m->device));
+      const int need_img = CAP_IMG * 8 + KEEP * 20 + 256 * 20, need_scale = CAP_SCALE * 8 + KEEP * 20 + 256 * 20;
+      const int need_post = KEEP * 44 + 256 * 20, need_r = (13552 + 3388) * 4, need_o = (16928 + 14112 + 6400) * 4;
+      (void)hipFuncSetAttribute((const void*)nms_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_img);
+      (void)hipFuncSetAttribute((const void*)nms_scale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_scale);
+      (void)hipFuncSetAttribute((const void*)stage2_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_post);
+      (void)hipFuncSetAttribute((const void*)stage3_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_post);
+      (void)hipFuncSetAttribute((const void*)rnet_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_r);
+      (void)hipFuncSetAttribute((const void*)onet_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_o);
+      (void)hipGetLastError();
+      if (lds_max < need_o) {
+        delete m;
+        return fail(VNF_E_INVALID, "mtcnn: device reports " + std::to_string(lds_max) + " B of LDS per workgroup, need " + std::to_string(need_o));
+      }
+    }
+    VNF_HIP(hipDeviceSynchronize());
+    *out = reinterpret_cast<vnf_handle>(static_cast<HandleBase*>(m));
+    return VNF_OK;
+  } catch (const std::exception& ex) {
+    return fail(VNF_E_INVALID, std::string("exception: ") + ex.what());
+  }
+}
+
+static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipStream_t s, std::vector<int>& cnt,
+                     std::vector<float>& fin) {
+  const vnf_mtcnn_cfg& cfg = m->cfg;
+  if (b > cfg.max_batch || H > cfg.max_height || W > cfg.max_width) return fail(VNF_E_CAPACITY, "mtcnn: frame batch exceeds handle capacity");
+  LevelTable t = make_levels(H, W, cfg.min_face_size, (double)cfg.factor);
+  m->last_table = t;
+  cnt.assign(b, 0);
+  fin.clear();
+  if (t.n == 0) return VNF_OK;  // image smaller than one cell: no detections
+  if ((size_t)t.tot_px > m->cap_px || (size_t)t.tot_p1 > m->cap_p1 || (size_t)t.tot_c2 > m->cap_c2 || (size_t)t.tot_out > m->cap_out)
+    return fail(VNF_E_CAPACITY, "mtcnn: pyramid exceeds handle capacity");
+  for (int l = 0; l < t.n; ++l)
+    if ((long long)t.l[l].oh * t.l[l].ow >= (1 << 20)) return fail(VNF_E_CAPACITY, "mtcnn: level too large for the 20-bit cell index");
+  const int B = b;
+  const size_t nseg = (size_t)MAX_LEVELS * cfg.max_batch;
+  VNF_HIP(hipMemsetAsync(m->cand_cnt, 0, (nseg * 2 + (size_t)cfg.max_batch * 3 + 16) * 4, s));
+  hipLaunchKernelGGL(pyramid_kernel, dim3((t.tot_px + 255) / 256, B), dim3(256), 0, s, frames, H, W, t, m->lvl);
+  hipLaunchKernelGGL(pnet_conv1_pool_kernel, dim3((t.tot_p1 + 255) / 256, B), dim3(256), 0, s, m->lvl, t, m->pw, m->p1);
+  hipLaunchKernelGGL(pnet_conv2_kernel, dim3((t.tot_c2 + 255) / 256, B), dim3(256), 0, s, m->p1, t, m->pw, m->c2);
+  hipLaunchKernelGGL(pnet_conv3_heads_kernel, dim3((t.tot_out + 255) / 256, B), dim3(256), 0, s, m->c2, t, m->pw,
+                     cfg.thresholds[0], B, m->cand, m->cand_cnt, m->status, m->prob_dbg, m->reg_dbg);
+  const size_t lds_scale = (size_t)CAP_SCALE * 8 + KEEP * 20 + 256 * 20;
+  const size_t lds_img = (size_t)CAP_IMG * 8 + KEEP * 20 + 256 * 20;
+  hipLaunchKernelGGL(nms_scale_kernel, dim3(t.n, B), dim3(256), lds_scale, s, m->cand, m->cand_cnt, t, B, 0.5f, m->keep1,
+                     m->keep1_cnt, m->status);
+  hipLaunchKernelGGL(nms_image_kernel, dim3(B), dim3(256), lds_img, s, m->keep1, m->keep1_cnt, t, B, 0.7f, W, H, m->rows,
+                     m->row_cnt, m->status);
+  VNF_HIP(hipGetLastError());
+  std::vector<int> h(cfg.max_batch * 3 + 16);
+  auto read_counts = [&]() -> int {
+    VNF_HIP(hipMemcpyAsync(h.data(), m->row_cnt, h.size() * 4, hipMemcpyDeviceToHost, s));
+    VNF_HIP(hipStreamSynchronize(s));
+    const int st = h[cfg.max_batch * 3];
+    if (st & (ST_OVER_SCALE | ST_OVER_IMG | ST_OVER_KEEP))
+      return fail(VNF_E_CAPACITY, "mtcnn: candidate table overflow (status " + std::to_string(st) + ")");
+    return VNF_OK;
+  };
+  int r = read_counts();
+  if (r != VNF_OK) return r;
+  int max2 = 0;
+  for (int i = 0; i < B; ++i) max2 = std::max(max2, h[i]);
+  if (max2 == 0) return VNF_OK;
+  // ---- stage 2
+  hipLaunchKernelGGL(crop_resize_kernel, dim3(max2, B), dim3(256), 0, s, frames, H, W, m->rows, m->row_cnt, 24, m->crops, m->status);
+  hipLaunchKernelGGL(rnet_kernel, dim3(max2, B), dim3(256), (13552 + 3388) * 4, s, m->crops, m->row_cnt, m->rw, m->rout);
+  const size_t lds_post = (size_t)KEEP * 28 + 256 * 20 + KEEP * 16;
+  hipLaunchKernelGGL(stage2_post_kernel, dim3(B), dim3(256), lds_post, s, m->rows, m->row_cnt, m->rout, cfg.thresholds[1], 0.7f,
+                     W, H, m->rows3, m->row3_cnt, m->status);
+  VNF_HIP(hipGetLastError());
+  r = read_counts();
+  if (r != VNF_OK) return r;
+  int max3 = 0;
+  for (int i = 0; i < B; ++i) max3 = std::max(max3, h[cfg.max_batch + i]);
+  if (max3 == 0) return VNF_OK;
+  // ---- stage 3
+  hipLaunchKernelGGL(crop_resize_kernel, dim3(max3, B), dim3(256), 0, s, frames, H, W, m->rows3, m->row3_cnt, 48, m->crops, m->status);
+  hipLaunchKernelGGL(onet_kernel, dim3(max3, B), dim3(512), (16928 + 14112 + 6400) * 4, s, m->crops, m->row3_cnt, m->ow, m->oout);
+  hipLaunchKernelGGL(stage3_post_kernel, dim3(B), dim3(256), lds_post, s, m->rows3, m->row3_cnt, m->oout, cfg.thresholds[2], 0.7f,
+                     cfg.select_largest, m->fin, m->fin_cnt, m->status);
+  VNF_HIP(hipGetLastError());
+  r = read_counts();
+  if (r != VNF_OK) return r;
+  int maxf = 0;
+  for (int i = 0; i < B; ++i) { cnt[i] = h[2 * cfg.max_batch + i]; maxf = std::max(maxf, cnt[i]); }
+  if (maxf == 0) return VNF_OK;
+  fin.resize((size_t)B * maxf * 15);
+  VNF_HIP(hipMemcpy2DAsync(fin.data(), (size_t)maxf * 15 * 4, m->fin, (size_t)KEEP * 15 * 4, (size_t)maxf * 15 * 4, B,
+                           hipMemcpyDeviceToHost, s));
+  VNF_HIP(hipStreamSynchronize(s));
+  return VNF_OK;
+}
+
+extern "C" int vnf_mtcnn_detect(vnf_handle h, const uint8_t* frames, int b, int height, int width, int32_t* counts,
+                                float* boxes, float* probs, float* points, int max_out, int32_t* n_out, void* stream) {
+  try {
+    HandleBase* hb = reinterpret_cast<HandleBase*>(h);
+    if (!hb || hb->kind != 3) return fail(VNF_E_INVALID, "not an MTCNN handle");
+    if (!frames || b <= 0 || !counts || !n_out) return fail(VNF_E_INVALID, "vnf_mtcnn_detect: bad argument");
+    Mtcnn* m = static_cast<Mtcnn*>(hb);
+    std::vector<int> cnt;
+    std::vector<float> fin;
+    int r = mtcnn_run(m, frames, b, height, width, (hipStream_t)stream, cnt, fin);
+    if (r != VNF_OK) return r;
+    int total = 0, maxf = 0;
+    for (int i = 0; i < b; ++i) { counts[i] = cnt[i]; total += cnt[i]; maxf = std::max(maxf, cnt[i]); }
+    *n_out = total;
+    if (total > max_out) return fail(VNF_E_CAPACITY, "vnf_mtcnn_detect: more faces than max_out");
+    int o = 0;
+    for (int i = 0; i < b; ++i)
+      for (int k = 0; k < cnt[i]; ++k, ++o) {
+        const float* f = &fin[((size_t)i * maxf + k) * 15];
+        if (boxes) memcpy(boxes + (size_t)o * 4, f, 16);
+        if (probs) probs[o] = f[4];
+        if (points) memcpy(points + (size_t)o * 10, f + 5, 40);
+      }
+    return VNF_OK;
+  } catch (const std::exception& ex) {
+    return fail(VNF_E_INVALID, std::string("exception: ") + ex.what());
+  }
+}
+
+// Staged-parity hook: dense P-Net maps of one pyramid level for frame 0 of a batch (test use).
+extern "C" int vnf_mtcnn_debug_pnet(vnf_handle h, const uint8_t* frames, int height, int width, int level,
+                                    float* level_out, float* prob_out, float* reg_out, int32_t dims[4], void* stream) {
+  try {
+    HandleBase* hb = reinterpret_cast<HandleBase*>(h);
+    if (!hb || hb->kind != 3) return fail(VNF_E_INVALID, "not an MTCNN handle");
+    Mtcnn* m = static_cast<Mtcnn*>(hb);
+    LevelTable t = make_levels(height, width, m->cfg.min_face_size, (double)m->cfg.factor);
+    if (level < 0 || level >= t.n) return fail(VNF_E_INVALID, "no such level");
+    float *pd = nullptr, *rd = nullptr;
+    VNF_HIP(hipMalloc(&pd, (size_t)t.tot_out * 4 * m->cfg.max_batch));
+    VNF_HIP(hipMalloc(&rd, (size_t)t.tot_out * 16 * m->cfg.max_batch));
+    m->prob_dbg = pd; m->reg_dbg = rd;
+    std::vector<int> cnt;
+    std::vector<float> fin;
+    int r = mtcnn_run(m, frames, 1, height, width, (hipStream_t)stream, cnt, fin);
+    m->prob_dbg = nullptr; m->reg_dbg = nullptr;
+    if (r == VNF_OK) {
+      const LevelDesc& L = t.l[level];
+      dims[0] = L.Hs; dims[1] = L.Ws; dims[2] = L.oh; dims[3] = L.ow;
+      hipError_t e = hipSuccess;
+      if (level_out)
+        for (int c = 0; c < 3 && e == hipSuccess; ++c)
+          e = hipMemcpy(level_out + (size_t)c * L.Hs * L.Ws, m->lvl + (size_t)c * t.tot_px + L.off_px, (size_t)L.Hs * L.Ws * 4, hipMemcpyDeviceToHost);
+      if (prob_out && e == hipSuccess) e = hipMemcpy(prob_out, pd + L.off_out, (size_t)L.oh * L.ow * 4, hipMemcpyDeviceToHost);
+      if (reg_out)
+        for (int c = 0; c < 4 && e == hipSuccess; ++c)
+          e = hipMemcpy(reg_out + (size_t)c * L.oh * L.ow, rd + (size_t)c * t.tot_out + L.off_out, (size_t)L.oh * L.ow * 4, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) r = fail(VNF_E_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(pd);
+    (void)hipFree(rd);
+    return r;
+  } catch (const std::exception& ex) {
+    return fail(VNF_E_INVALID, std::string("exception: ") + ex.what());
+  }
+}

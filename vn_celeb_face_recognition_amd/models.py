@@ -3,6 +3,7 @@ encoder and classifier classes with getattr(models, <name>)(**json_kwargs)
 (demo_image.py:361-374, demo_video.py:260-273, find_embedding.py:77)."""
 from .encoders import InceptionResnetV1, iresnet100  # noqa: F401
 from .classifier import MLPModel  # noqa: F401
+from .detector import MTCNN  # noqa: F401
 
 
 def _out_of_scope(name, why):
