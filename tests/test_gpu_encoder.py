@@ -96,3 +96,39 @@ def test_encoder_refuses_cpu():
     m = InceptionResnetV1(pretrained=None).eval()
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 160, 160))
+
+
+def test_ir100_f32_matches_reference_golden():
+    """IR-100 swap-in (config 5), fp32 path vs features produced by the reference itself.  Features
+    are not normalised (|y| ~ 2.5): the gate is 1e-4 relative to the feature scale per row."""
+    from vn_celeb_face_recognition_amd.models import iresnet100
+    g = np.load(os.path.join(GOLDEN, "ir100_seed0.npz"))
+    x = seeded_normal((2, 3, 112, 112), g["input_seed"])
+    m = iresnet100(pretrained=False, compute_dtype="f32", max_batch=2).to("cuda:0").eval()
+    y = m(x.cuda()).cpu().numpy()
+    err = np.linalg.norm(y - g["features"], axis=1) / np.linalg.norm(g["features"], axis=1)
+    assert err.max() <= 1e-4, err
+
+
+def test_ir100_stage_taps_and_bf16(irv1_sd):
+    from vn_celeb_face_recognition_amd.models import iresnet100
+    from vn_celeb_face_recognition_amd.weights import generate_state_dict
+    from oracle import iresnet
+    sd = generate_state_dict("iresnet100", 0, as_torch=True)
+    x = seeded_normal((3, 3, 112, 112), 21)
+    taps = {}
+    ref = iresnet.iresnet_forward(sd, x, taps=taps).numpy()
+    m = iresnet100(pretrained=False, compute_dtype="f32", max_batch=3).to("cuda:0").eval()
+    y = m(x.cuda()).cpu().numpy()
+    for name in ["stem", "layer1", "layer2", "layer3", "layer4"]:
+        got, want = m.tap(name, 3), taps[name].numpy()
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), name
+    assert (np.linalg.norm(y - ref, axis=1) / np.linalg.norm(ref, axis=1)).max() <= 1e-4
+    mb = iresnet100(pretrained=False, compute_dtype="bf16", max_batch=3).to("cuda:0").eval()
+    yb = mb(x.cuda()).cpu().numpy()
+    rel = np.linalg.norm(yb - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    print("ir100 bf16 relative L2 error vs fp32 oracle:", rel)
+    assert rel.max() <= 5e-2
+    cos = (yb * ref).sum(axis=1) / np.linalg.norm(yb, axis=1) / np.linalg.norm(ref, axis=1)
+    assert cos.min() >= 0.998

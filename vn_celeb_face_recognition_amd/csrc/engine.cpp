@@ -430,9 +430,128 @@ int add_linear(Encoder& e, const std::string& name, const float* w, const float*
   return add_conv(e, s);
 }
 
+// IResNet-100 (models/iresnet_encoder.py:26-61, 64-159).  Per IBasicBlock two launches:
+//   A: conv1(bn1(x)) -> bn2 -> PReLU.  bn1 sits BEFORE a zero-padded conv, so it cannot be folded
+//      into a plain bias: its scale goes into the weights, and its shift becomes a bias that depends
+//      on which taps fall inside the image -- one of 9 border classes, picked in the epilogue.
+//      bn2 folds into per-output scale / bias, PReLU runs in the epilogue.
+//   B: conv2 (stride) -> bn3, + identity (x, or the 1x1-stride-2 downsample branch with its BN).
+// The head (bn2 -> flatten (C,H,W) -> fc -> features BN1d) is ONE 7x7 "convolution" over the
+// NHWC map: fc.weight viewed as (512, 512, 7, 7) is exactly that conv's weight.
 int build_ir100(Encoder& e, WeightMap& wm) {
-  (void)e; (void)wm;
-  return fail(VNF_E_INVALID, "IR-100 plan not built yet");
+  e.in_size = 112;
+  const float EPS = 2e-5f;
+  const int b_in = e.add_buf(112, 112, 8);
+  { Op op; op.kind = Op::PACK; op.a = b_in; e.ops.push_back(op); }
+  const int planes[4] = {64, 128, 256, 512}, nblk[4] = {3, 13, 30, 3};
+  int H = 112;
+  int x = e.add_buf(112, 112, 64);
+  {  // stem: conv1 3x3 p1 (3->64) -> bn1 -> PReLU (iresnet_encoder.py:140-142)
+    ConvSpec s;
+    s.name = "conv1"; s.x_buf = b_in; s.cin = 3; s.cin_pad = 8; s.KH = s.KW = 3; s.ph = s.pw = 1;
+    s.pieces.resize(1);
+    Piece& pc = s.pieces[0];
+    pc.w = wm.get("conv1.weight", 64 * 27);
+    pc.cout = pc.cout_pad = 64;
+    const float* sl = wm.get("prelu.weight", 64);
+    NEED(pc.w && sl && bn_fold(wm, "bn1", 64, EPS, pc.scale, pc.bias));
+    pc.slope.assign(sl, sl + 64);
+    s.segs.push_back({0, 64, x, 0});
+    s.act = ACT_PRELU;
+    TRY(add_conv(e, s));
+  }
+  e.taps["stem"] = {x, 0, 64};
+  int cin = 64;
+  std::vector<int> stage_end;
+  for (int li = 0; li < 4; ++li) {
+    const int P = planes[li], Ho = H / 2;
+    const int t_first = e.add_buf(H, H, P);      // conv1 output of the first block (input resolution)
+    const int t_rest = e.add_buf(Ho, Ho, P);
+    const int dsb = e.add_buf(Ho, Ho, P);        // downsample branch
+    const int y[2] = {e.add_buf(Ho, Ho, P), e.add_buf(Ho, Ho, P)};
+    int cur = -1;
+    for (int b = 0; b < nblk[li]; ++b) {
+      const std::string p = "layer" + std::to_string(li + 1) + "." + std::to_string(b);
+      const int xin = b == 0 ? x : y[cur];
+      const int xout = b == 0 ? y[0] : y[cur ^ 1];
+      const int ci = b == 0 ? cin : P, t1 = b == 0 ? t_first : t_rest, st = b == 0 ? 2 : 1;
+      std::vector<float> s1, t1v;
+      NEED(bn_fold(wm, p + ".bn1", ci, EPS, s1, t1v));
+      {
+        ConvSpec s;
+        s.name = p + ".conv1"; s.x_buf = xin; s.cin = s.cin_pad = ci; s.KH = s.KW = 3; s.ph = s.pw = 1;
+        s.pieces.resize(1);
+        Piece& pc = s.pieces[0];
+        pc.w = wm.get(p + ".conv1.weight", (int64_t)P * ci * 9);
+        pc.cout = pc.cout_pad = P;
+        const float* sl = wm.get(p + ".prelu.weight", P);
+        NEED(pc.w && sl && bn_fold(wm, p + ".bn2", P, EPS, pc.scale, pc.bias));
+        pc.slope.assign(sl, sl + P);
+        s.pre_s = &s1; s.pre_t = &t1v;
+        s.segs.push_back({0, P, t1, 0});
+        s.act = ACT_PRELU;
+        TRY(add_conv(e, s));
+      }
+      if (b == 0) {
+        ConvSpec s;
+        s.name = p + ".downsample"; s.x_buf = xin; s.cin = s.cin_pad = ci; s.sh = s.sw = 2;
+        s.pieces.resize(1);
+        Piece& pc = s.pieces[0];
+        pc.w = wm.get(p + ".downsample.0.weight", (int64_t)P * ci);
+        pc.cout = pc.cout_pad = P;
+        NEED(pc.w && bn_fold(wm, p + ".downsample.1", P, EPS, pc.scale, pc.bias));
+        s.segs.push_back({0, P, dsb, 0});
+        s.act = ACT_NONE;
+        TRY(add_conv(e, s));
+      }
+      {
+        ConvSpec s;
+        s.name = p + ".conv2"; s.x_buf = t1; s.cin = s.cin_pad = P; s.KH = s.KW = 3; s.ph = s.pw = 1; s.sh = s.sw = st;
+        s.pieces.resize(1);
+        Piece& pc = s.pieces[0];
+        pc.w = wm.get(p + ".conv2.weight", (int64_t)P * P * 9);
+        pc.cout = pc.cout_pad = P;
+        NEED(pc.w && bn_fold(wm, p + ".bn3", P, EPS, pc.scale, pc.bias));
+        s.segs.push_back({0, P, xout, 0});
+        s.res_buf = b == 0 ? dsb : xin;
+        s.act = ACT_NONE;
+        TRY(add_conv(e, s));
+      }
+      cur = b == 0 ? 0 : cur ^ 1;
+    }
+    x = y[cur];
+    e.taps["layer" + std::to_string(li + 1)] = {x, 0, P};
+    cin = P;
+    H = Ho;
+    stage_end.push_back((int)e.ops.size());
+  }
+  {  // bn2 -> flatten -> fc(+bias) -> features (iresnet_encoder.py:149-153)
+    std::vector<float> s2, t2, sf, tf;
+    NEED(bn_fold(wm, "bn2", 512, EPS, s2, t2) && bn_fold(wm, "features", 512, EPS, sf, tf));
+    ConvSpec s;
+    s.name = "fc"; s.x_buf = x; s.cin = s.cin_pad = 512; s.KH = s.KW = 7;
+    s.pieces.resize(1);
+    Piece& pc = s.pieces[0];
+    pc.w = wm.get("fc.weight", (int64_t)512 * 25088);
+    const float* fb = wm.get("fc.bias", 512);
+    NEED(pc.w && fb);
+    pc.cout = pc.cout_pad = 512;
+    pc.scale = sf;
+    pc.bias.resize(512);
+    for (int i = 0; i < 512; ++i) pc.bias[i] = fb[i] * sf[i] + tf[i];
+    s.pre_s = &s2; s.pre_t = &t2;
+    s.segs.push_back({0, 512, -2, 0});
+    s.act = ACT_NONE; s.out_f32 = 1;
+    TRY(add_conv(e, s));
+  }
+  { Op op; op.kind = Op::COPYOUT; e.ops.push_back(op); }
+  int c1 = 32, c2 = 64;
+  if (const char* c = getenv("VNF_IR100_CHUNK1")) c1 = atoi(c) > 0 ? atoi(c) : c1;
+  if (const char* c = getenv("VNF_IR100_CHUNK2")) c2 = atoi(c) > 0 ? atoi(c) : c2;
+  e.groups.push_back({0, stage_end[0], c1});
+  e.groups.push_back({stage_end[0], stage_end[1], c2});
+  e.groups.push_back({stage_end[1], (int)e.ops.size(), 1 << 30});
+  return VNF_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -515,6 +634,10 @@ int Encoder::run(const void* x, int n, int x_dtype, float* out, hipStream_t s, s
           case Op::L2NORM:
             VNF_HIP(launch_l2norm(emb_raw + (size_t)n0 * 512, out + (size_t)n0 * 512, nn, 512, s));
             break;
+          case Op::COPYOUT:
+            VNF_HIP(hipMemcpyAsync(out + (size_t)n0 * 512, emb_raw + (size_t)n0 * 512, (size_t)nn * 512 * 4,
+                                   hipMemcpyDeviceToDevice, s));
+            break;
         }
       }
     }
@@ -544,7 +667,7 @@ int Encoder::run(const void* x, int n, int x_dtype, float* out, hipStream_t s, s
         snprintf(line, sizeof line, "%-28s conv M/img=%-6d N=%-5d K=%-5d %dx%d s%d  %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n",
                  L.name.c_str(), L.Ho * L.Wo, L.cout, L.K, L.KH, L.KW, L.sh, ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
       } else {
-        static const char* kn[] = {"pack", "conv", "maxpool", "avgpool", "l2norm"};
+        static const char* kn[] = {"pack", "conv", "maxpool", "avgpool", "l2norm", "copyout"};
         snprintf(line, sizeof line, "%-28s %-8s %60s %8.4f ms\n", "", kn[op.kind], "", ms[oi]);
       }
       *report += line;

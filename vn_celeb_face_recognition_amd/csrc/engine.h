@@ -68,7 +68,7 @@ struct ConvLayer {
 };
 
 struct Op {
-  enum Kind { PACK, CONV, MAXPOOL, AVGPOOL, L2NORM } kind;
+  enum Kind { PACK, CONV, MAXPOOL, AVGPOOL, L2NORM, COPYOUT } kind;
   int a = 0, b = 0, c = 0, d = 0, e = 0;  // meaning per kind (see engine.cpp)
 };
 
