@@ -133,6 +133,48 @@ def recognize_celeb(bth_alg_face_list, device, emb_model, classify_model, transf
     return bth_names
 
 
+class FacePipeline:
+    """detect -> align -> embed -> classify with every intermediate resident in HBM.
+
+    One call per frame batch (demo_video.py:86-129 without the host round trips): frames are
+    uploaded once, vnf_mtcnn_detect leaves boxes/landmarks for vnf_align, the warp writes the
+    normalised NCHW batch straight in the encoder's input dtype, and only names, boxes and
+    (optionally) embeddings come back."""
+
+    def __init__(self, detector, encoder, classifier, label2name, target_size, threshold=0.0):
+        self.detector, self.encoder, self.classifier = detector, encoder, classifier
+        self.label2name = label2name
+        self.size = int(target_size)
+        self.template = center_point_dict[str((self.size, self.size))]
+        self.threshold = threshold
+        self.in_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16}.get(
+            getattr(encoder, "compute_dtype", "f32"), torch.float32)
+
+    def embed_frames(self, frames_dev):
+        """frames_dev (B,H,W,3) u8 cuda -> (counts, boxes (n,4) host, embeddings (n,512) cuda)."""
+        counts, boxes, probs, points = self.detector.detect_device(frames_dev)
+        n = int(boxes.shape[0])
+        if n == 0:
+            return counts, boxes, torch.empty((0, 512), dtype=torch.float32, device=frames_dev.device)
+        fidx = np.repeat(np.arange(len(counts), dtype=np.int32), counts)
+        _, faces = align_faces_device(frames_dev, fidx, boxes, points, self.template, self.size, want_u8=False,
+                                      norm_dtype=self.in_dtype)
+        return counts, boxes, self.encoder(faces)
+
+    def recognize_frames(self, rgb_images):
+        """list of equal-size HWC u8 RGB frames (or a (B,H,W,3) array / cuda tensor) ->
+        (per-frame name lists, per-frame box lists, embeddings (n,512) cuda)."""
+        frames, _ = self.detector._to_device_frames(rgb_images)
+        counts, boxes, emb = self.embed_frames(frames)
+        names = identify_person(emb, self.classifier, self.label2name, self.threshold) if emb.shape[0] else []
+        bth_names, bth_boxes, o = [], [], 0
+        for c in counts:
+            bth_names.append(names[o:o + c])
+            bth_boxes.append([boxes[k] for k in range(o, o + c)])
+            o += c
+        return bth_names, bth_boxes, emb
+
+
 def get_face_from_boxes(image, boxes, box_requirements=None):
     """demo_image.py:174-199 (host views, no arithmetic)."""
     list_faces, face_idx = [], []
