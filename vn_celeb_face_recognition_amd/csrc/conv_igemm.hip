@@ -5,12 +5,21 @@
 //   co = output channel                     -> "channel" axis, BN per workgroup
 //   k  = (kh, kw, c) flattened, c fastest  -> walked in 128-byte K tiles
 // A is never materialised: every 16-byte k-chunk (8 x 16-bit or 4 x f32 channels of one filter tap)
-// is gathered straight from the NHWC input with a per-chunk offset table (ktab), zero-filled at
-// padded borders.  Both operands are staged global -> registers -> LDS (double-buffered, one
-// barrier per K tile; the next tile's global loads are in flight under the MFMAs of the current
-// one), in 128-byte rows whose 16-byte chunks are XOR-swizzled with (row & 7) so that the
-// ds_write_b128 of the loader and the ds_read_b128 of the fragment reads are both bank-conflict
-// free on CDNA4's 64-bank LDS (checked exhaustively).
+// is gathered straight from the NHWC input with a per-chunk offset table (ktab); padded borders
+// and rows past M read a 16-byte zero page instead.
+//
+// Main kernel (conv_igemm_dma_kernel): both operands go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, one 1-KiB piece = 8 rows x 128 B per wave instruction), never through
+// VGPRs, into a ring of S stages.  The per-lane SOURCE address carries both the im2col gather and
+// the bank swizzle (the LDS image must be lane-linear: physical 16-byte slot p of row r holds
+// logical k-chunk p ^ (r & 7)), so the ds_read_b128 fragment reads are conflict-free on CDNA4's
+// 64-bank LDS (checked exhaustively).  S-1 tiles are in flight under the MFMAs of the
+// current one: counted s_waitcnt vmcnt(N) + one raw s_barrier per K tile, no VGPR staging cost,
+// so bytes-in-flight per CU -- what bounds these small-K, small-N problems -- is set by LDS
+// capacity (160 KiB) instead of by register pressure.
+//
+// Fallback kernel (conv_igemm_kernel): register-staged double buffering, used when the gather
+// table does not fit LDS (IR-100's 25088-deep fc).
 //
 // The MFMA is issued with the WEIGHT fragment as the A operand and the ACTIVATION fragment as
 // the B operand, so an accumulator register quad holds 4 consecutive output channels of one
@@ -21,6 +30,8 @@
 //
 // dtype paths: bf16 / f16 -> v_mfma_f32_16x16x32_{bf16,f16}; f32 -> v_mfma_f32_16x16x4_f32
 // (exact f32 FMA chain; the <=1e-4 parity path).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace vnf {
@@ -36,6 +47,7 @@ struct KArgs {  // device-side copy of ConvArgs (POD)
   const int4* ktab;
   const char* res;
   const float* slope;
+  const char* zero;  // >= 16 zero bytes
   int ldx, H, W, Ho, Wo, sh, sw, ph, pw;
   int K, Kpad, nkt;
   int ncls, cout_pad;
@@ -114,33 +126,90 @@ __device__ __forceinline__ void store8<float>(char* p, const float (&v)[8]) {
   *reinterpret_cast<f32x4_t*>(p + 16) = b;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const KArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// XCD-aware, bijective block -> tile map: blocks that share an XCD (same blockIdx % 8) walk
+// consecutive tiles, so the BN-column siblings of one pixel tile hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---- epilogue shared by both kernels: fp32 accumulators -> LDS -> whole NHWC rows ------------
+template <typename T, int BM, int BN, int WM, int WN, int LDS_BYTES>
+__device__ __forceinline__ void conv_epilogue(const KArgs& a, f32x4_t (&acc)[BM / WM / 16][BN / WN / 16], char* smem,
+                                              int m0, int n0) {
   constexpr int ES = (int)sizeof(T);
-  constexpr int CH = 16 / ES;    // elements per 16-byte chunk
-  constexpr int BKE = 128 / ES;  // elements per K tile
-  constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int TM = WTM / 16, TN = WTN / 16;
-  constexpr int AP = BM / 32, BP = BN / 32;
-  constexpr int STAGE = (BM + BN) * 128;
-  static_assert(WM * WN == 4, "4 waves per workgroup");
-
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = wave / WN, wn = wave % WN, frow = lane & 15, fgrp = lane >> 4;
+  const int HoWo = a.Ho * a.Wo;
+  int sg = 0;
+#pragma unroll
+  for (int s = 1; s < 4; ++s)
+    if (s < a.nseg && n0 >= a.seg_c0[s]) sg = s;
+  char* const dptr = a.seg_ptr[sg];
+  const int dld = a.seg_ld[sg], dc0 = a.seg_c0[sg];
 
-  // XCD-aware, bijective block -> tile map: blocks that share an XCD (same blockIdx % 8) walk
-  // consecutive tiles, so the BN-column siblings of one pixel tile hit the same L2.
-  int bid = blockIdx.x;
-  {
-    const int q = a.nblk >> 3, r = a.nblk & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  float* sC = reinterpret_cast<float*>(smem);
+  constexpr int CST = BN + 4;  // floats per staged row (+16 B pad: conflict-free float4 writes)
+  constexpr int CPR = BN / 8;  // 8-channel chunks per row
+  // as many wave rows per pass as the staging LDS holds
+  constexpr int EPASS = (BM * CST * 4 <= LDS_BYTES) ? 1 : WM;
+  constexpr int RPP = BM / EPASS;
+  static_assert(RPP * CST * 4 <= LDS_BYTES, "epilogue staging does not fit");
+  for (int pass = 0; pass < EPASS; ++pass) {
+    if ((wm * WTM) / RPP == pass) {
+      const int rbase = wm * WTM - pass * RPP;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          *reinterpret_cast<f32x4_t*>(sC + (rbase + i * 16 + frow) * CST + wn * WTN + j * 16 + fgrp * 4) = acc[i][j];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < RPP * CPR; idx += 256) {
+      const int r = idx / CPR, cc = idx - r * CPR;
+      const int m = m0 + pass * RPP + r, c = n0 + cc * 8;
+      if (m < a.M && c < a.Cout) {
+        float v[8];
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(sC + r * CST + cc * 8);
+        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(sC + r * CST + cc * 8 + 4);
+        int cls = 0;
+        if (a.ncls == 9) {
+          const int rr = m % HoWo, ho = rr / a.Wo, wo = rr - ho * a.Wo;
+          cls = (ho == 0 ? 0 : (ho == a.Ho - 1 ? 2 : 1)) * 3 + (wo == 0 ? 0 : (wo == a.Wo - 1 ? 2 : 1));
+        }
+        const float* bp = a.bias + (size_t)cls * a.cout_pad + c;
+        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bp), b1 = *reinterpret_cast<const f32x4_t*>(bp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = v0[e] + b0[e]; v[4 + e] = v1[e] + b1[e]; }
+        if (a.res) {
+          float rv[8];
+          load8<T>(a.res + ((size_t)m * a.ldres + c) * ES, rv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        if (a.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (a.act == ACT_PRELU) {
+          const float* sp = a.slope + c;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sp[e];
+        }
+        if (a.out_f32)
+          store8<float>(dptr + ((size_t)m * dld + (c - dc0)) * 4, v);
+        else
+          store8<T>(dptr + ((size_t)m * dld + (c - dc0)) * ES, v);
+      }
+    }
+    __syncthreads();
   }
-  const int tile_m = bid / a.tiles_n, tile_n = bid - tile_m * a.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+}
 
-  const int lrow = tid >> 3, lcol = tid & 7;
-  int abase[AP], ahi[AP], awi[AP];
+// per-thread pixel-row bookkeeping: thread (tid>>3) owns rows lrow + 32*p of the A tile
+template <int AP>
+__device__ __forceinline__ void row_setup(const KArgs& a, int m0, int lrow, int (&abase)[AP], int (&ahi)[AP],
+                                          int (&awi)[AP]) {
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int p = 0; p < AP; ++p) {
@@ -157,6 +226,146 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const KArgs a) {
       abase[p] = 0;
     }
   }
+}
+
+// fragment reads + MFMAs of one K tile held in LDS (A rows at sA, weight rows at sB)
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void tile_mma(const char* sA, const char* sB, int arow0, int brow0, int frow, int fgrp,
+                                         int kleft, f32x4_t (&acc)[TM][TN]) {
+  constexpr int BKE = 128 / (int)sizeof(T);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    if (ks * (BKE / 2) < kleft) {
+      uint4 xf[TM], wf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = arow0 + i * 16 + frow;
+        xf[i] = *reinterpret_cast<const uint4*>(sA + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = brow0 + j * 16 + frow;
+        wf[j] = *reinterpret_cast<const uint4*>(sB + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], wf[j], xf[i]);
+    }
+  }
+}
+
+// ===================================================================== LDS-DMA ring kernel
+// One LDS-DMA piece: 64 lanes x 16 B -> lds_base + lane*16.  M0 carries the LDS base; it is
+// compiler-reserved, so it is saved and restored inside the statement (cdna guide 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+
+// Retire this wave's older DMA pieces (all but the N youngest), drain its own LDS reads of the
+// stage about to be recycled, then meet the other waves.  One statement, so the compiler cannot
+// move LDS accesses between the wait and the barrier.
+template <int N>
+__device__ __forceinline__ void wait_dma_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int S>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = (int)sizeof(T);
+  constexpr int CH = 16 / ES, BKE = 128 / ES;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
+  constexpr int AP = BM / 32, BP = BN / 32, L = AP + BP;  // DMA pieces per wave per K tile
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(WM * WN == 4 && S >= 3, "4 waves, ring of >= 3 stages");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = xcd_remap(blockIdx.x, a.nblk);
+  const int tile_m = bid / a.tiles_n, tile_n = bid - tile_m * a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nkt = a.nkt;
+
+  // gather table -> LDS (behind the ring), so the K loop issues no VGPR-destination global load
+  int4* sK = reinterpret_cast<int4*>(smem + S * STAGE);
+  for (int i = tid; i < nkt * 8; i += 256) sK[i] = a.ktab[i];
+
+  const int lrow = tid >> 3, lcol = tid & 7;
+  const int lchunk = lcol ^ (lrow & 7);  // logical k-chunk this lane fetches (physical slot = lcol)
+  int abase[AP], ahi[AP], awi[AP];
+  row_setup<AP>(a, m0, lrow, abase, ahi, awi);
+  const char* wsrc = a.w + ((size_t)(n0 + lrow) * a.Kpad + lchunk * CH) * ES;
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);  // LDS byte address of the ring
+
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();  // gather table visible
+
+  auto issue = [&](int kt) {
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((kt % S) * STAGE) + (unsigned)(wave * 1024));
+    const int4 e = sK[kt * 8 + lchunk];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const int hi = ahi[p] + e.y, wi = awi[p] + e.z;
+      const bool ok = e.w && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      const char* src = ok ? a.x + (size_t)(abase[p] + e.x) * ES : a.zero;
+      glds16(src, sbase + p * 4096);
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p)
+      glds16(wsrc + ((size_t)(32 * p) * a.Kpad + (size_t)kt * BKE) * ES, sbase + BM * 128 + p * 4096);
+  };
+
+#pragma unroll
+  for (int t = 0; t < S - 1; ++t)
+    if (t < nkt) issue(t);
+
+  const int frow = lane & 15, fgrp = lane >> 4;
+  for (int kt = 0; kt < nkt; ++kt) {
+    // tile kt has landed once at most the S-2 younger tiles of this wave are still in flight
+    if (kt + S - 2 < nkt)
+      wait_dma_and_barrier<(S - 2) * L>();
+    else
+      wait_dma_and_barrier<0>();
+    // every wave's pieces of tile kt have landed; stage (kt-1)%S is free for tile kt+S-1
+    if (kt + S - 1 < nkt) issue(kt + S - 1);
+    const char* sA = smem + (kt % S) * STAGE;
+    tile_mma<T, TM, TN>(sA, sA + BM * 128, wm * WTM, wn * WTN, frow, fgrp, a.K - kt * BKE, acc);
+  }
+  __syncthreads();
+  conv_epilogue<T, BM, BN, WM, WN, S * STAGE>(a, acc, smem, m0, n0);
+}
+
+// ===================================================================== register-staged fallback
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = (int)sizeof(T);
+  constexpr int CH = 16 / ES, BKE = 128 / ES;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
+  constexpr int AP = BM / 32, BP = BN / 32;
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = xcd_remap(blockIdx.x, a.nblk);
+  const int tile_m = bid / a.tiles_n, tile_n = bid - tile_m * a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int lrow = tid >> 3, lcol = tid & 7;
+  int abase[AP], ahi[AP], awi[AP];
+  row_setup<AP>(a, m0, lrow, abase, ahi, awi);
   const char* wrow = a.w + ((size_t)(n0 + lrow) * a.Kpad + lcol * CH) * ES;
 
   f32x4_t acc[TM][TN];
@@ -201,96 +410,47 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const KArgs a) {
     const int st = kt & 1;
     if (kt + 1 < a.nkt) gload(kt + 1);
     const char* sA = smem + st * STAGE;
-    const char* sB = sA + BM * 128;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (kt * BKE + ks * (BKE / 2) < a.K) {
-        uint4 xf[TM], wf[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int row = wm * WTM + i * 16 + frow;
-          xf[i] = *reinterpret_cast<const uint4*>(sA + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int row = wn * WTN + j * 16 + frow;
-          wf[j] = *reinterpret_cast<const uint4*>(sB + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], wf[j], xf[i]);
-      }
-    }
+    tile_mma<T, TM, TN>(sA, sA + BM * 128, wm * WTM, wn * WTN, frow, fgrp, a.K - kt * BKE, acc);
     if (kt + 1 < a.nkt) lstore(st ^ 1);
     __syncthreads();
   }
+  conv_epilogue<T, BM, BN, WM, WN, 2 * STAGE>(a, acc, smem, m0, n0);
+}
 
-  // ---- epilogue: fp32 accumulators -> LDS -> whole NHWC rows ------------------------------
-  int sg = 0;
-#pragma unroll
-  for (int s = 1; s < 4; ++s)
-    if (s < a.nseg && n0 >= a.seg_c0[s]) sg = s;
-  char* const dptr = a.seg_ptr[sg];
-  const int dld = a.seg_ld[sg], dc0 = a.seg_c0[sg];
-
-  float* sC = reinterpret_cast<float*>(smem);
-  constexpr int CST = BN + 4;  // floats per staged row (+16 B pad: conflict-free float4 writes)
-  constexpr int CPR = BN / 8;  // 8-channel chunks per row
-  for (int pass = 0; pass < WM; ++pass) {
-    if (wm == pass) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          *reinterpret_cast<f32x4_t*>(sC + (i * 16 + frow) * CST + wn * WTN + j * 16 + fgrp * 4) = acc[i][j];
-    }
-    __syncthreads();
-    for (int idx = tid; idx < WTM * CPR; idx += 256) {
-      const int r = idx / CPR, cc = idx - r * CPR;
-      const int m = m0 + pass * WTM + r, c = n0 + cc * 8;
-      if (m < a.M && c < a.Cout) {
-        float v[8];
-        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(sC + r * CST + cc * 8);
-        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(sC + r * CST + cc * 8 + 4);
-        int cls = 0;
-        if (a.ncls == 9) {
-          const int rr = m % HoWo, ho = rr / a.Wo, wo = rr - ho * a.Wo;
-          cls = (ho == 0 ? 0 : (ho == a.Ho - 1 ? 2 : 1)) * 3 + (wo == 0 ? 0 : (wo == a.Wo - 1 ? 2 : 1));
-        }
-        const float* bp = a.bias + (size_t)cls * a.cout_pad + c;
-        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bp), b1 = *reinterpret_cast<const f32x4_t*>(bp + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = v0[e] + b0[e]; v[4 + e] = v1[e] + b1[e]; }
-        if (a.res) {
-          float rv[8];
-          load8<T>(a.res + ((size_t)m * a.ldres + c) * ES, rv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rv[e];
-        }
-        if (a.act == ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (a.act == ACT_PRELU) {
-          const float* sp = a.slope + c;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sp[e];
-        }
-        if (a.out_f32)
-          store8<float>(dptr + ((size_t)m * dld + (c - dc0)) * 4, v);
-        else
-          store8<T>(dptr + ((size_t)m * dld + (c - dc0)) * ES, v);
-      }
-    }
-    __syncthreads();
+// ===================================================================== host launch
+static const char* zero_page() {  // per-device 256 zero bytes for padded / out-of-range gather sources
+  static char* z[16] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!z[dev]) {
+    if (hipMalloc((void**)&z[dev], 256) != hipSuccess) return nullptr;
+    (void)hipMemset(z[dev], 0, 256);
   }
+  return z[dev];
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int S>
+static hipError_t launch_dma(const KArgs& k, hipStream_t s) {
+  constexpr int ring = S * (BM + BN) * 128;
+  static bool attr_done = false;
+  KArgs kk = k;
+  const int lds = ring + k.nkt * 8 * 16;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN, WM, WN, S>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  const int tiles_m = (k.M + BM - 1) / BM;
+  kk.tiles_n = (k.Cout + BN - 1) / BN;
+  kk.nblk = tiles_m * kk.tiles_n;
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<T, BM, BN, WM, WN, S>), dim3(kk.nblk), dim3(256), lds, s, kk);
+  return hipGetLastError();
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
-static hipError_t launch_cfg(const KArgs& k, hipStream_t s) {
-  constexpr int stage = 2 * (BM + BN) * 128;
-  constexpr int epi = (BM / WM) * (BN + 4) * 4;
-  constexpr int lds = stage > epi ? stage : epi;
+static hipError_t launch_reg(const KArgs& k, hipStream_t s) {
+  constexpr int lds = 2 * (BM + BN) * 128;
   KArgs kk = k;
   const int tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.Cout + BN - 1) / BN;
@@ -301,31 +461,44 @@ static hipError_t launch_cfg(const KArgs& k, hipStream_t s) {
 
 template <typename T>
 static hipError_t launch_typed(const ConvArgs& a, const KArgs& k, hipStream_t s) {
+  static const int env_bm = getenv("VNF_BM") ? atoi(getenv("VNF_BM")) : 0;
+  static const int env_bn = getenv("VNF_BN") ? atoi(getenv("VNF_BN")) : 0;
+  static const int env_reg = getenv("VNF_CONV_REG") ? atoi(getenv("VNF_CONV_REG")) : 0;
   // BN must divide every segment boundary so a tile maps to exactly one destination
-  int bn = a.bn;
+  auto fits = [&](int b) {
+    for (int i = 0; i < a.nseg; ++i)
+      if (a.seg[i].c0 % b) return false;
+    return true;
+  };
+  int bn = a.bn ? a.bn : env_bn;
+  if (bn && !fits(bn)) bn = 0;  // incompatible override: fall back to the heuristic
   if (bn == 0) {
     bn = 128;
-    auto fits = [&](int b) {
-      for (int i = 0; i < a.nseg; ++i)
-        if (a.seg[i].c0 % b) return false;
-      return true;
-    };
     while (bn > 32 && !(fits(bn) && (a.Cout % bn == 0 || a.Cout > 2 * bn))) bn >>= 1;
     if (!fits(bn)) return hipErrorInvalidValue;
     // keep at least ~2 workgroups per CU in flight when the problem allows it
     auto blocks = [&](int bm_, int bn_) { return ((a.M + bm_ - 1) / bm_) * ((a.Cout + bn_ - 1) / bn_); };
     while (bn > 64 && blocks(128, bn) < 512) bn >>= 1;
   }
-  int bm = a.bm;
+  int bm = a.bm ? a.bm : env_bm;
   if (bm == 0) {
     bm = 128;
     if (bn <= 64 && ((a.M + 127) / 128) * ((a.Cout + bn - 1) / bn) < 512) bm = 64;
   }
-  if (bm == 128 && bn == 128) return launch_cfg<T, 128, 128, 2, 2>(k, s);
-  if (bm == 128 && bn == 64) return launch_cfg<T, 128, 64, 2, 2>(k, s);
-  if (bm == 128 && bn == 32) return launch_cfg<T, 128, 32, 4, 1>(k, s);
-  if (bm == 64 && bn == 64) return launch_cfg<T, 64, 64, 2, 2>(k, s);
-  if (bm == 64 && bn == 32) return launch_cfg<T, 64, 32, 2, 2>(k, s);
+  const bool dma = !env_reg && k.zero && k.nkt * 8 * 16 <= 24 * 1024;
+  if (dma) {
+    if (bm == 128 && bn == 128) return launch_dma<T, 128, 128, 2, 2, 3>(k, s);
+    if (bm == 128 && bn == 64) return launch_dma<T, 128, 64, 2, 2, 3>(k, s);
+    if (bm == 128 && bn == 32) return launch_dma<T, 128, 32, 4, 1, 3>(k, s);
+    if (bm == 64 && bn == 64) return launch_dma<T, 64, 64, 2, 2, 4>(k, s);
+    if (bm == 64 && bn == 32) return launch_dma<T, 64, 32, 2, 2, 4>(k, s);
+    return hipErrorInvalidValue;
+  }
+  if (bm == 128 && bn == 128) return launch_reg<T, 128, 128, 2, 2>(k, s);
+  if (bm == 128 && bn == 64) return launch_reg<T, 128, 64, 2, 2>(k, s);
+  if (bm == 128 && bn == 32) return launch_reg<T, 128, 32, 4, 1>(k, s);
+  if (bm == 64 && bn == 64) return launch_reg<T, 64, 64, 2, 2>(k, s);
+  if (bm == 64 && bn == 32) return launch_reg<T, 64, 32, 2, 2>(k, s);
   return hipErrorInvalidValue;
 }
 
@@ -336,7 +509,7 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t s) {
   if (a.Cout % 8 || a.Kpad % bke || a.nseg < 1 || a.nseg > 4) return hipErrorInvalidValue;
   KArgs k;
   k.x = (const char*)a.x; k.w = (const char*)a.w; k.bias = a.bias; k.ktab = a.ktab;
-  k.res = (const char*)a.res; k.slope = a.slope;
+  k.res = (const char*)a.res; k.slope = a.slope; k.zero = zero_page();
   k.ldx = a.ldx; k.H = a.H; k.W = a.W; k.Ho = a.Ho; k.Wo = a.Wo;
   k.sh = a.sh; k.sw = a.sw; k.ph = a.ph; k.pw = a.pw;
   k.K = a.K; k.Kpad = a.Kpad; k.nkt = a.Kpad / bke;
