@@ -156,7 +156,33 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, f32x4_t (&acc)[BM 
   constexpr int EPASS = (BM * CST * 4 <= LDS_BYTES) ? 1 : WM;
   constexpr int RPP = BM / EPASS;
   static_assert(RPP * CST * 4 <= LDS_BYTES, "epilogue staging does not fit");
+  // Each thread owns ONE 8-channel column chunk and NIT rows per pass (compile-time trip count), so
+  // the bias is loaded once and every residual load of a pass is in flight before the barrier.
+  constexpr int NIT = RPP * CPR / 256, RSTEP = 256 / CPR;
+  static_assert(RPP * CPR % 256 == 0 && 256 % CPR == 0, "epilogue thread map");
+  const int cc = tid % CPR, r0 = tid / CPR;
+  const int c = n0 + cc * 8;
+  const bool cok = c < a.Cout;
+  const int cl = cok ? c : 0;  // in-range column for the loads of masked threads
+  f32x4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  float slope[8];
+  if (a.ncls == 1) {
+    b0 = *reinterpret_cast<const f32x4_t*>(a.bias + cl);
+    b1 = *reinterpret_cast<const f32x4_t*>(a.bias + cl + 4);
+  }
+  if (a.act == ACT_PRELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) slope[e] = a.slope[cl + e];
+  }
   for (int pass = 0; pass < EPASS; ++pass) {
+    float rv[NIT][8];
+    if (a.res) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int m = min(m0 + pass * RPP + r0 + it * RSTEP, a.M - 1);
+        load8<T>(a.res + ((size_t)m * a.ldres + cl) * ES, rv[it]);
+      }
+    }
     if ((wm * WTM) / RPP == pass) {
       const int rbase = wm * WTM - pass * RPP;
 #pragma unroll
@@ -166,36 +192,35 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, f32x4_t (&acc)[BM 
           *reinterpret_cast<f32x4_t*>(sC + (rbase + i * 16 + frow) * CST + wn * WTN + j * 16 + fgrp * 4) = acc[i][j];
     }
     __syncthreads();
-    for (int idx = tid; idx < RPP * CPR; idx += 256) {
-      const int r = idx / CPR, cc = idx - r * CPR;
-      const int m = m0 + pass * RPP + r, c = n0 + cc * 8;
-      if (m < a.M && c < a.Cout) {
-        float v[8];
-        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(sC + r * CST + cc * 8);
-        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(sC + r * CST + cc * 8 + 4);
-        int cls = 0;
-        if (a.ncls == 9) {
-          const int rr = m % HoWo, ho = rr / a.Wo, wo = rr - ho * a.Wo;
-          cls = (ho == 0 ? 0 : (ho == a.Ho - 1 ? 2 : 1)) * 3 + (wo == 0 ? 0 : (wo == a.Wo - 1 ? 2 : 1));
-        }
-        const float* bp = a.bias + (size_t)cls * a.cout_pad + c;
-        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bp), b1 = *reinterpret_cast<const f32x4_t*>(bp + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = v0[e] + b0[e]; v[4 + e] = v1[e] + b1[e]; }
-        if (a.res) {
-          float rv[8];
-          load8<T>(a.res + ((size_t)m * a.ldres + c) * ES, rv);
+    for (int it = 0; it < NIT; ++it) {
+      const int r = r0 + it * RSTEP;
+      const int m = m0 + pass * RPP + r;
+      float v[8];
+      const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(sC + r * CST + cc * 8);
+      const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(sC + r * CST + cc * 8 + 4);
+      if (a.ncls == 9) {
+        const int mm = min(m, a.M - 1);
+        const int rr = mm % HoWo, ho = rr / a.Wo, wo = rr - ho * a.Wo;
+        const int cls = (ho == 0 ? 0 : (ho == a.Ho - 1 ? 2 : 1)) * 3 + (wo == 0 ? 0 : (wo == a.Wo - 1 ? 2 : 1));
+        const float* bp = a.bias + (size_t)cls * a.cout_pad + cl;
+        b0 = *reinterpret_cast<const f32x4_t*>(bp);
+        b1 = *reinterpret_cast<const f32x4_t*>(bp + 4);
+      }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rv[e];
-        }
-        if (a.act == ACT_RELU) {
+      for (int e = 0; e < 4; ++e) { v[e] = v0[e] + b0[e]; v[4 + e] = v1[e] + b1[e]; }
+      if (a.res) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (a.act == ACT_PRELU) {
-          const float* sp = a.slope + c;
+        for (int e = 0; e < 8; ++e) v[e] += rv[it][e];
+      }
+      if (a.act == ACT_RELU) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sp[e];
-        }
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (a.act == ACT_PRELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope[e];
+      }
+      if (m < a.M && cok) {
         if (a.out_f32)
           store8<float>(dptr + ((size_t)m * dld + (c - dc0)) * 4, v);
         else
@@ -459,40 +484,69 @@ static hipError_t launch_reg(const KArgs& k, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Tile configurations of the LDS-DMA kernel: {BM, BN, waves along M, waves along N, ring stages}.
+struct TileCfg { int bm, bn, wm, wn, s; };
+static const TileCfg kCfgs[] = {
+    {128, 128, 2, 2, 3}, {128, 64, 2, 2, 3}, {128, 32, 4, 1, 3}, {64, 64, 2, 2, 4}, {64, 32, 2, 2, 4},
+    {256, 32, 4, 1, 3},  {256, 64, 4, 1, 3}, {64, 128, 1, 4, 3}, {32, 64, 2, 2, 4}, {32, 128, 1, 4, 4},
+    {128, 64, 2, 2, 4},  {64, 64, 2, 2, 3},  {128, 32, 4, 1, 4},
+};
+constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
+
+int conv_num_cfgs() { return kNumCfgs; }
+
+static bool dma_capable(const ConvArgs& a) { return (a.Kpad / (128 / dtype_size(a.dtype))) * 8 * 16 <= 24 * 1024; }
+
+bool conv_cfg_ok(const ConvArgs& a, int cfg) {
+  if (cfg < 0 || cfg >= kNumCfgs || !dma_capable(a)) return false;
+  const TileCfg& c = kCfgs[cfg];
+  for (int i = 0; i < a.nseg; ++i)
+    if (a.seg[i].c0 % c.bn) return false;  // a tile must map to exactly one destination tensor
+  if (c.bn > 32 && a.Cout <= c.bn / 2) return false;  // more than half the tile would be padding
+  const int lds = c.s * (c.bm + c.bn) * 128 + (a.Kpad / (128 / dtype_size(a.dtype))) * 8 * 16;
+  return lds <= 160 * 1024;
+}
+
+template <typename T>
+static hipError_t launch_cfg(int cfg, const KArgs& k, hipStream_t s) {
+  switch (cfg) {
+    case 0: return launch_dma<T, 128, 128, 2, 2, 3>(k, s);
+    case 1: return launch_dma<T, 128, 64, 2, 2, 3>(k, s);
+    case 2: return launch_dma<T, 128, 32, 4, 1, 3>(k, s);
+    case 3: return launch_dma<T, 64, 64, 2, 2, 4>(k, s);
+    case 4: return launch_dma<T, 64, 32, 2, 2, 4>(k, s);
+    case 5: return launch_dma<T, 256, 32, 4, 1, 3>(k, s);
+    case 6: return launch_dma<T, 256, 64, 4, 1, 3>(k, s);
+    case 7: return launch_dma<T, 64, 128, 1, 4, 3>(k, s);
+    case 8: return launch_dma<T, 32, 64, 2, 2, 4>(k, s);
+    case 9: return launch_dma<T, 32, 128, 1, 4, 4>(k, s);
+    case 10: return launch_dma<T, 128, 64, 2, 2, 4>(k, s);
+    case 11: return launch_dma<T, 64, 64, 2, 2, 3>(k, s);
+    case 12: return launch_dma<T, 128, 32, 4, 1, 4>(k, s);
+  }
+  return hipErrorInvalidValue;
+}
+
 template <typename T>
 static hipError_t launch_typed(const ConvArgs& a, const KArgs& k, hipStream_t s) {
-  static const int env_bm = getenv("VNF_BM") ? atoi(getenv("VNF_BM")) : 0;
-  static const int env_bn = getenv("VNF_BN") ? atoi(getenv("VNF_BN")) : 0;
   static const int env_reg = getenv("VNF_CONV_REG") ? atoi(getenv("VNF_CONV_REG")) : 0;
-  // BN must divide every segment boundary so a tile maps to exactly one destination
+  if (a.cfg >= 0 && !env_reg && k.zero && conv_cfg_ok(a, a.cfg)) return launch_cfg<T>(a.cfg, k, s);
+  // heuristic: BN must divide every segment boundary; keep ~2 workgroups per CU when possible
   auto fits = [&](int b) {
     for (int i = 0; i < a.nseg; ++i)
       if (a.seg[i].c0 % b) return false;
     return true;
   };
-  int bn = a.bn ? a.bn : env_bn;
-  if (bn && !fits(bn)) bn = 0;  // incompatible override: fall back to the heuristic
-  if (bn == 0) {
-    bn = 128;
-    while (bn > 32 && !(fits(bn) && (a.Cout % bn == 0 || a.Cout > 2 * bn))) bn >>= 1;
-    if (!fits(bn)) return hipErrorInvalidValue;
-    // keep at least ~2 workgroups per CU in flight when the problem allows it
-    auto blocks = [&](int bm_, int bn_) { return ((a.M + bm_ - 1) / bm_) * ((a.Cout + bn_ - 1) / bn_); };
-    while (bn > 64 && blocks(128, bn) < 512) bn >>= 1;
-  }
-  int bm = a.bm ? a.bm : env_bm;
-  if (bm == 0) {
-    bm = 128;
-    if (bn <= 64 && ((a.M + 127) / 128) * ((a.Cout + bn - 1) / bn) < 512) bm = 64;
-  }
-  const bool dma = !env_reg && k.zero && k.nkt * 8 * 16 <= 24 * 1024;
-  if (dma) {
-    if (bm == 128 && bn == 128) return launch_dma<T, 128, 128, 2, 2, 3>(k, s);
-    if (bm == 128 && bn == 64) return launch_dma<T, 128, 64, 2, 2, 3>(k, s);
-    if (bm == 128 && bn == 32) return launch_dma<T, 128, 32, 4, 1, 3>(k, s);
-    if (bm == 64 && bn == 64) return launch_dma<T, 64, 64, 2, 2, 4>(k, s);
-    if (bm == 64 && bn == 32) return launch_dma<T, 64, 32, 2, 2, 4>(k, s);
-    return hipErrorInvalidValue;
+  int bn = 128;
+  while (bn > 32 && !(fits(bn) && (a.Cout % bn == 0 || a.Cout > 2 * bn))) bn >>= 1;
+  if (!fits(bn)) return hipErrorInvalidValue;
+  auto blocks = [&](int bm_, int bn_) { return ((a.M + bm_ - 1) / bm_) * ((a.Cout + bn_ - 1) / bn_); };
+  while (bn > 64 && blocks(128, bn) < 512) bn >>= 1;
+  int bm = 128;
+  if (bn <= 64 && blocks(128, bn) < 512) bm = 64;
+  if (!env_reg && k.zero && dma_capable(a)) {
+    const int id = bm == 128 ? (bn == 128 ? 0 : bn == 64 ? 1 : 2) : (bn == 64 ? 3 : 4);
+    return launch_cfg<T>(id, k, s);
   }
   if (bm == 128 && bn == 128) return launch_reg<T, 128, 128, 2, 2>(k, s);
   if (bm == 128 && bn == 64) return launch_reg<T, 128, 64, 2, 2>(k, s);

@@ -87,17 +87,90 @@ int Encoder::add_buf(int H, int W, int C) {
   return (int)bufs.size() - 1;
 }
 
+ConvArgs Encoder::conv_args(const ConvLayer& L, int n0, int nn) const {
+  const int es = dtype_size(dtype);
+  const Buf& xb = bufs[L.x_buf];
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dtype = dtype;
+  a.x = xb.ptr + ((size_t)n0 * xb.elems_per_image() + L.x_coff) * es;
+  a.ldx = xb.C; a.H = L.H; a.W = L.W; a.Cin = L.cin; a.Ho = L.Ho; a.Wo = L.Wo;
+  a.KH = L.KH; a.KW = L.KW; a.sh = L.sh; a.sw = L.sw; a.ph = L.ph; a.pw = L.pw;
+  a.w = L.w; a.K = L.K; a.Kpad = L.Kpad; a.bias = L.bias; a.ncls = L.ncls; a.cout_pad = L.cout_pad;
+  a.ktab = L.ktab; a.M = nn * L.Ho * L.Wo; a.Cout = L.cout; a.nseg = L.nseg;
+  for (int i = 0; i < L.nseg; ++i) {
+    a.seg[i].c0 = L.seg[i].c0; a.seg[i].c1 = L.seg[i].c1;
+    if (L.seg[i].buf == -2) {
+      a.seg[i].ptr = emb_raw + (size_t)n0 * 512;
+      a.seg[i].ld = 512;
+    } else {
+      const Buf& ob = bufs[L.seg[i].buf];
+      a.seg[i].ptr = ob.ptr + ((size_t)n0 * ob.elems_per_image() + L.seg[i].coff) * (L.out_f32 ? 4 : es);
+      a.seg[i].ld = ob.C;
+    }
+  }
+  if (L.res_buf >= 0) {
+    const Buf& rb = bufs[L.res_buf];
+    a.res = rb.ptr + ((size_t)n0 * rb.elems_per_image() + L.res_coff) * es;
+    a.ldres = rb.C;
+  }
+  a.act = L.act; a.slope = L.slope; a.out_f32 = L.out_f32;
+  a.cfg = L.cfg;
+  return a;
+}
+
+// Pick each convolution's tile configuration by timing the candidates on this device at the
+// batch size it will see (measure, don't guess: the best tile depends on M, N, K, the number of
+// workgroups and where the operands sit in the cache hierarchy).  ~1 s at create time.
+int Encoder::autotune() {
+  static const int enabled = getenv("VNF_AUTOTUNE") ? atoi(getenv("VNF_AUTOTUNE")) : 1;
+  if (!enabled) return VNF_OK;
+  hipEvent_t e0, e1;
+  VNF_HIP(hipEventCreate(&e0));
+  VNF_HIP(hipEventCreate(&e1));
+  for (const Group& g : groups) {
+    const int nn = g.chunk < max_batch ? g.chunk : max_batch;
+    for (int oi = g.first; oi < g.last; ++oi) {
+      if (ops[oi].kind != Op::CONV) continue;
+      ConvLayer& L = convs[ops[oi].a];
+      float best = 1e30f;
+      int best_cfg = -1;
+      for (int cfg = -1; cfg < conv_num_cfgs(); ++cfg) {
+        ConvArgs a = conv_args(L, 0, nn);
+        a.cfg = cfg;
+        if (cfg >= 0 && !conv_cfg_ok(a, cfg)) continue;
+        if (launch_conv(a, 0) != hipSuccess) { (void)hipGetLastError(); continue; }
+        const int reps = 3;
+        VNF_HIP(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; ++r) (void)launch_conv(a, 0);
+        VNF_HIP(hipEventRecord(e1, 0));
+        VNF_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        VNF_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) { best = ms; best_cfg = cfg; }
+      }
+      L.cfg = best_cfg;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return VNF_OK;
+}
+
 int Encoder::finalize() {
   const int es = dtype_size(dtype);
   for (auto& b : bufs) {
-    b.ptr = (char*)dalloc(b.elems_per_image() * es * (size_t)max_batch);
+    const size_t bytes = b.elems_per_image() * es * (size_t)max_batch;
+    b.ptr = (char*)dalloc(bytes);
     if (!b.ptr) return VNF_E_HIP;
+    VNF_HIP(hipMemset(b.ptr, 0, bytes));
   }
   emb_raw = (float*)dalloc((size_t)max_batch * 512 * 4);
   if (!emb_raw) return VNF_E_HIP;
   macs_alg = macs_exec = 0;
   for (auto& c : convs) { macs_alg += c.macs_alg; macs_exec += c.macs_exec; }
-  return VNF_OK;
+  if (groups.empty()) groups.push_back({0, (int)ops.size(), 1 << 30});
+  return autotune();
 }
 
 struct Piece {  // output channels contributed by one reference conv / linear
@@ -586,32 +659,7 @@ int Encoder::run(const void* x, int n, int x_dtype, float* out, hipStream_t s, s
           }
           case Op::CONV: {
             const ConvLayer& L = convs[op.a];
-            const Buf& xb = bufs[L.x_buf];
-            ConvArgs a;
-            memset(&a, 0, sizeof(a));
-            a.dtype = dtype;
-            a.x = xb.ptr + ((size_t)n0 * xb.elems_per_image() + L.x_coff) * es;
-            a.ldx = xb.C; a.H = L.H; a.W = L.W; a.Cin = L.cin; a.Ho = L.Ho; a.Wo = L.Wo;
-            a.KH = L.KH; a.KW = L.KW; a.sh = L.sh; a.sw = L.sw; a.ph = L.ph; a.pw = L.pw;
-            a.w = L.w; a.K = L.K; a.Kpad = L.Kpad; a.bias = L.bias; a.ncls = L.ncls; a.cout_pad = L.cout_pad;
-            a.ktab = L.ktab; a.M = nn * L.Ho * L.Wo; a.Cout = L.cout; a.nseg = L.nseg;
-            for (int i = 0; i < L.nseg; ++i) {
-              a.seg[i].c0 = L.seg[i].c0; a.seg[i].c1 = L.seg[i].c1;
-              if (L.seg[i].buf == -2) {
-                a.seg[i].ptr = emb_raw + (size_t)n0 * 512;
-                a.seg[i].ld = 512;
-              } else {
-                const Buf& ob = bufs[L.seg[i].buf];
-                a.seg[i].ptr = ob.ptr + ((size_t)n0 * ob.elems_per_image() + L.seg[i].coff) * (L.out_f32 ? 4 : es);
-                a.seg[i].ld = ob.C;
-              }
-            }
-            if (L.res_buf >= 0) {
-              const Buf& rb = bufs[L.res_buf];
-              a.res = rb.ptr + ((size_t)n0 * rb.elems_per_image() + L.res_coff) * es;
-              a.ldres = rb.C;
-            }
-            a.act = L.act; a.slope = L.slope; a.out_f32 = L.out_f32;
+            const ConvArgs a = conv_args(L, n0, nn);
             hipError_t err = launch_conv(a, s);
             if (err != hipSuccess) return fail(VNF_E_HIP, L.name + ": " + hipGetErrorString(err));
             break;
@@ -664,8 +712,8 @@ int Encoder::run(const void* x, int n, int x_dtype, float* out, hipStream_t s, s
       if (op.kind == Op::CONV) {
         const ConvLayer& L = convs[op.a];
         const double gf = 2.0 * L.macs_alg * n / 1e9;
-        snprintf(line, sizeof line, "%-28s conv M/img=%-6d N=%-5d K=%-5d %dx%d s%d  %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n",
-                 L.name.c_str(), L.Ho * L.Wo, L.cout, L.K, L.KH, L.KW, L.sh, ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
+        snprintf(line, sizeof line, "%-28s conv M/img=%-6d N=%-5d K=%-5d %dx%d s%d cfg%-2d %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n",
+                 L.name.c_str(), L.Ho * L.Wo, L.cout, L.K, L.KH, L.KW, L.sh, L.cfg, ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
       } else {
         static const char* kn[] = {"pack", "conv", "maxpool", "avgpool", "l2norm", "copyout"};
         snprintf(line, sizeof line, "%-28s %-8s %60s %8.4f ms\n", "", kn[op.kind], "", ms[oi]);

@@ -64,6 +64,7 @@ struct ConvLayer {
   struct { int c0, c1, buf, coff; } seg[4];
   int res_buf = -1, res_coff = 0;
   int act = ACT_NONE, out_f32 = 0;
+  int cfg = -1;  // tile configuration chosen by Encoder::autotune (-1 = launcher heuristic)
   double macs_alg = 0, macs_exec = 0;  // per image
 };
 
@@ -87,7 +88,9 @@ struct Encoder : HandleBase {
   double macs_alg = 0, macs_exec = 0;
 
   int add_buf(int H, int W, int C);
-  int finalize();  // allocate buffers
+  int finalize();  // allocate buffers, autotune tile configurations
+  int autotune();
+  ConvArgs conv_args(const ConvLayer& L, int n0, int nn) const;
   int run(const void* x, int n, int x_dtype, float* out, hipStream_t s, std::string* report = nullptr);
 };
 

@@ -40,10 +40,12 @@ struct ConvArgs {
   int act;
   const float* slope;   // PReLU slopes [Cout_pad]
   int out_f32;          // store fp32 instead of dtype
-  int bm, bn;           // tile choice (0 = heuristic)
+  int cfg;              // tile configuration id (conv_cfg_ok), -1 = heuristic
 };
 
 hipError_t launch_conv(const ConvArgs& a, hipStream_t s);
+int conv_num_cfgs();
+bool conv_cfg_ok(const ConvArgs& a, int cfg);  // is tile configuration `cfg` usable for this convolution
 
 // NCHW (n,3,S,S) of x_dtype -> NHWC8 of dtype (channels 3..7 zero)
 hipError_t launch_pack_input(const void* x, int x_dtype, void* out, int dtype, int n, int hw, hipStream_t s);

@@ -44,7 +44,6 @@ extern "C" int vnf_mlp_create(const vnf_tensor_desc* weights, int n_weights, int
     if (r == VNF_OK) r = add_linear(e, "dense_2", w2, b2, 2048, num_classes, m->cpad, m->b_h, m->b_logit, ACT_NONE);
     if (r == VNF_OK) r = e.finalize();
     if (r != VNF_OK) { delete m; return r; }
-    e.groups.push_back({0, (int)e.ops.size(), 1 << 30});
     VNF_HIP(hipDeviceSynchronize());
     *out = reinterpret_cast<vnf_handle>(static_cast<HandleBase*>(m));
     return VNF_OK;
