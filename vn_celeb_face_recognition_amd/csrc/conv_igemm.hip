@@ -139,6 +139,7 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, f32x4_t (&acc)[BM 
                                               int m0, int n0) {
   constexpr int ES = (int)sizeof(T);
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
+  constexpr int NT = WM * WN * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, frow = lane & 15, fgrp = lane >> 4;
   const int HoWo = a.Ho * a.Wo;
@@ -158,8 +159,8 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, f32x4_t (&acc)[BM 
   static_assert(RPP * CST * 4 <= LDS_BYTES, "epilogue staging does not fit");
   // Each thread owns ONE 8-channel column chunk and NIT rows per pass (compile-time trip count), so
   // the bias is loaded once and every residual load of a pass is in flight before the barrier.
-  constexpr int NIT = RPP * CPR / 256, RSTEP = 256 / CPR;
-  static_assert(RPP * CPR % 256 == 0 && 256 % CPR == 0, "epilogue thread map");
+  constexpr int NIT = RPP * CPR / NT, RSTEP = NT / CPR;
+  static_assert(RPP * CPR % NT == 0 && NT % CPR == 0, "epilogue thread map");
   const int cc = tid % CPR, r0 = tid / CPR;
   const int c = n0 + cc * 8;
   const bool cok = c < a.Cout;
@@ -231,14 +232,14 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, f32x4_t (&acc)[BM 
   }
 }
 
-// per-thread pixel-row bookkeeping: thread (tid>>3) owns rows lrow + 32*p of the A tile
-template <int AP>
+// per-thread pixel-row bookkeeping: thread (tid>>3) owns rows lrow + RS*p of the A tile
+template <int AP, int RS>
 __device__ __forceinline__ void row_setup(const KArgs& a, int m0, int lrow, int (&abase)[AP], int (&ahi)[AP],
                                           int (&awi)[AP]) {
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int p = 0; p < AP; ++p) {
-    const int m = m0 + lrow + 32 * p;
+    const int m = m0 + lrow + RS * p;
     if (m < a.M) {
       const int n = m / HoWo, r = m - n * HoWo;
       const int ho = r / a.Wo, wo = r - ho * a.Wo;
@@ -301,14 +302,15 @@ __device__ __forceinline__ void wait_dma_and_barrier() {
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int S>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const KArgs a) {
+__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const KArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = (int)sizeof(T);
   constexpr int CH = 16 / ES, BKE = 128 / ES;
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
-  constexpr int AP = BM / 32, BP = BN / 32, L = AP + BP;  // DMA pieces per wave per K tile
+  constexpr int NW = WM * WN, NT = NW * 64, RS = NT / 8;  // waves, threads, tile rows covered per DMA pass
+  constexpr int AP = BM / RS, BP = BN / RS, L = AP + BP;  // DMA pieces per wave per K tile
   constexpr int STAGE = (BM + BN) * 128;
-  static_assert(WM * WN == 4 && S >= 3, "4 waves, ring of >= 3 stages");
+  static_assert((NW == 4 || NW == 8) && S >= 3 && BM % RS == 0 && BN % RS == 0, "4 or 8 waves, ring of >= 3 stages");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -320,12 +322,12 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const KArgs a) {
 
   // gather table -> LDS (behind the ring), so the K loop issues no VGPR-destination global load
   int4* sK = reinterpret_cast<int4*>(smem + S * STAGE);
-  for (int i = tid; i < nkt * 8; i += 256) sK[i] = a.ktab[i];
+  for (int i = tid; i < nkt * 8; i += NT) sK[i] = a.ktab[i];
 
   const int lrow = tid >> 3, lcol = tid & 7;
   const int lchunk = lcol ^ (lrow & 7);  // logical k-chunk this lane fetches (physical slot = lcol)
   int abase[AP], ahi[AP], awi[AP];
-  row_setup<AP>(a, m0, lrow, abase, ahi, awi);
+  row_setup<AP, RS>(a, m0, lrow, abase, ahi, awi);
   const char* wsrc = a.w + ((size_t)(n0 + lrow) * a.Kpad + lchunk * CH) * ES;
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);  // LDS byte address of the ring
 
@@ -344,11 +346,11 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const KArgs a) {
       const int hi = ahi[p] + e.y, wi = awi[p] + e.z;
       const bool ok = e.w && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
       const char* src = ok ? a.x + (size_t)(abase[p] + e.x) * ES : a.zero;
-      glds16(src, sbase + p * 4096);
+      glds16(src, sbase + p * (NW * 1024));
     }
 #pragma unroll
     for (int p = 0; p < BP; ++p)
-      glds16(wsrc + ((size_t)(32 * p) * a.Kpad + (size_t)kt * BKE) * ES, sbase + BM * 128 + p * 4096);
+      glds16(wsrc + ((size_t)(RS * p) * a.Kpad + (size_t)kt * BKE) * ES, sbase + BM * 128 + p * (NW * 1024));
   };
 
 #pragma unroll
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const KArgs a) {
 
   const int lrow = tid >> 3, lcol = tid & 7;
   int abase[AP], ahi[AP], awi[AP];
-  row_setup<AP>(a, m0, lrow, abase, ahi, awi);
+  row_setup<AP, 32>(a, m0, lrow, abase, ahi, awi);
   const char* wrow = a.w + ((size_t)(n0 + lrow) * a.Kpad + lcol * CH) * ES;
 
   f32x4_t acc[TM][TN];
@@ -469,7 +471,7 @@ static hipError_t launch_dma(const KArgs& k, hipStream_t s) {
   const int tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.Cout + BN - 1) / BN;
   kk.nblk = tiles_m * kk.tiles_n;
-  hipLaunchKernelGGL((conv_igemm_dma_kernel<T, BM, BN, WM, WN, S>), dim3(kk.nblk), dim3(256), lds, s, kk);
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<T, BM, BN, WM, WN, S>), dim3(kk.nblk), dim3(WM * WN * 64), lds, s, kk);
   return hipGetLastError();
 }
 
@@ -490,6 +492,9 @@ static const TileCfg kCfgs[] = {
     {128, 128, 2, 2, 3}, {128, 64, 2, 2, 3}, {128, 32, 4, 1, 3}, {64, 64, 2, 2, 4}, {64, 32, 2, 2, 4},
     {256, 32, 4, 1, 3},  {256, 64, 4, 1, 3}, {64, 128, 1, 4, 3}, {32, 64, 2, 2, 4}, {32, 128, 1, 4, 4},
     {128, 64, 2, 2, 4},  {64, 64, 2, 2, 3},  {128, 32, 4, 1, 4},
+    // 8-wave workgroups: two waves per SIMD, so one wave's DMA issue / LDS reads hide under the other's MFMAs
+    {128, 128, 2, 4, 3}, {256, 128, 4, 2, 3}, {256, 64, 4, 2, 3}, {128, 64, 4, 2, 3}, {128, 256, 2, 4, 3},
+    {128, 128, 2, 4, 4},
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -503,6 +508,7 @@ bool conv_cfg_ok(const ConvArgs& a, int cfg) {
   for (int i = 0; i < a.nseg; ++i)
     if (a.seg[i].c0 % c.bn) return false;  // a tile must map to exactly one destination tensor
   if (c.bn > 32 && a.Cout <= c.bn / 2) return false;  // more than half the tile would be padding
+  if (a.cout_pad % c.bn) return false;                // weight rows n0..n0+BN-1 must exist in the packed buffer
   const int lds = c.s * (c.bm + c.bn) * 128 + (a.Kpad / (128 / dtype_size(a.dtype))) * 8 * 16;
   return lds <= 160 * 1024;
 }
@@ -523,6 +529,12 @@ static hipError_t launch_cfg(int cfg, const KArgs& k, hipStream_t s) {
     case 10: return launch_dma<T, 128, 64, 2, 2, 4>(k, s);
     case 11: return launch_dma<T, 64, 64, 2, 2, 3>(k, s);
     case 12: return launch_dma<T, 128, 32, 4, 1, 4>(k, s);
+    case 13: return launch_dma<T, 128, 128, 2, 4, 3>(k, s);
+    case 14: return launch_dma<T, 256, 128, 4, 2, 3>(k, s);
+    case 15: return launch_dma<T, 256, 64, 4, 2, 3>(k, s);
+    case 16: return launch_dma<T, 128, 64, 4, 2, 3>(k, s);
+    case 17: return launch_dma<T, 128, 256, 2, 4, 3>(k, s);
+    case 18: return launch_dma<T, 128, 128, 2, 4, 4>(k, s);
   }
   return hipErrorInvalidValue;
 }
