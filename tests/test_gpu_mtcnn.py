@@ -123,3 +123,27 @@ def test_detect_then_align_resident_pipeline_matches_oracle():
     for f, wnt in zip(faces[0], want):
         diff = np.abs(f.astype(np.int32) - wnt.astype(np.int32))
         assert (diff > 2).mean() < 0.01
+
+
+def test_pyramid_fast_path_bit_exact_and_synthetic_1080p_batch():
+    """Rows of W*3 % 16 == 0 take the vectorised pyramid kernel: levels must stay bit-identical to
+    interpolate(mode='area'); and a batch of synthetic 1080p frames finds every pasted face."""
+    from vn_celeb_face_recognition_amd.models import MTCNN
+    from vn_celeb_face_recognition_amd.synth import make_frames
+    img = load_image("hoai_linh_4_recog.jpg")           # 1280 x 720
+    h, w = img.shape[:2]
+    det = MTCNN(min_face_size=50, device="cuda:0", max_batch=1, max_height=h, max_width=w)
+    scales = om.scale_pyramid(h, w, 50, 0.709)
+    x = torch.from_numpy(img.copy()).permute(2, 0, 1).unsqueeze(0).float()
+    for li in (0, 3, len(scales) - 1):
+        lvl, prob, reg = det.debug_pnet_level(img, li)
+        want = (om.imresample(x, om.level_size(h, w, scales[li])) - 127.5) * 0.0078125
+        assert np.array_equal(lvl, want[0].numpy()), li
+    frames, truth = make_frames(2, 6, seed=3)
+    det2 = MTCNN(keep_all=True, min_face_size=50, device="cuda:0", max_batch=2)
+    boxes, probs = det2.inference(list(frames), landmark=False)
+    for b, t in zip(boxes, truth):
+        assert len(b) >= len(t)
+        for (x0, y0, x1, y1) in t:                       # every pasted crop contains a detection centre
+            cx, cy = (np.asarray(b)[:, 0] + np.asarray(b)[:, 2]) / 2, (np.asarray(b)[:, 1] + np.asarray(b)[:, 3]) / 2
+            assert ((cx > x0) & (cx < x1) & (cy > y0) & (cy < y1)).any()

@@ -98,6 +98,66 @@ __global__ void pyramid_kernel(const uint8_t* __restrict__ frames, int H, int W,
   o[2 * (size_t)t.tot_px] = ((s2 / kh) / kw - 127.5f) * 0.0078125f;
 }
 
+// Fast path of K1 for rows that are a whole number of 16-byte chunks (W*3 % 16 == 0: 1920, 1280, 640 ...).
+// One workgroup per (output row of any level, frame): every lane streams 16-byte chunks of the input
+// rows of that bin row (fully coalesced; each level re-reads the u8 frame once, from L2 / Infinity
+// Cache after the first), keeps per-byte column sums in registers, parks them in LDS, and the
+// output pixels then add their horizontal spans.  Integer sums, so the result is bit-identical to
+// the per-pixel kernel above and to the oracle.
+__global__ void __launch_bounds__(256) pyramid_rows_kernel(const uint8_t* __restrict__ frames, int H, int W,
+                                                            LevelTable t, float* __restrict__ lvl) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned* colsum = reinterpret_cast<unsigned*>(smem);  // W*3 entries
+  int li = 0, r = blockIdx.x;
+  while (li + 1 < t.n && r >= t.l[li].Hs) { r -= t.l[li].Hs; ++li; }
+  const LevelDesc L = t.l[li];
+  const int img = blockIdx.y, i = r;
+  const int h0 = (int)(((long long)i * H) / L.Hs), h1 = (int)((((long long)(i + 1)) * H + L.Hs - 1) / L.Hs);
+  const int rowb = W * 3, nchunk = rowb >> 4;
+  const uint8_t* base = frames + (size_t)img * H * rowb;
+  for (int c0 = 0; c0 < nchunk; c0 += 512) {   // 2 chunks per thread per sweep
+    unsigned acc[2][16];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[q][j] = 0u;
+    const int ca = c0 + threadIdx.x, cb = ca + 256;
+    for (int yy = h0; yy < h1; ++yy) {
+      const uint4* row = reinterpret_cast<const uint4*>(base + (size_t)yy * rowb);
+      uint4 va = ca < nchunk ? row[ca] : uint4{0u, 0u, 0u, 0u};
+      uint4 vb = cb < nchunk ? row[cb] : uint4{0u, 0u, 0u, 0u};
+      const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0][d * 4 + e] += (wa[d] >> (8 * e)) & 0xFFu;
+          acc[1][d * 4 + e] += (wb[d] >> (8 * e)) & 0xFFu;
+        }
+    }
+    if (ca < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) colsum[ca * 16 + j] = acc[0][j];
+    }
+    if (cb < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) colsum[cb * 16 + j] = acc[1][j];
+    }
+  }
+  __syncthreads();
+  const float kh = (float)(h1 - h0);
+  for (int x = threadIdx.x; x < L.Ws; x += blockDim.x) {
+    const int w0 = (int)(((long long)x * W) / L.Ws), w1 = (int)((((long long)(x + 1)) * W + L.Ws - 1) / L.Ws);
+    unsigned s0 = 0, s1 = 0, s2 = 0;
+    for (int xx = w0; xx < w1; ++xx) { s0 += colsum[3 * xx]; s1 += colsum[3 * xx + 1]; s2 += colsum[3 * xx + 2]; }
+    const float kw = (float)(w1 - w0);
+    float* o = lvl + ((size_t)img * 3) * t.tot_px + L.off_px + i * L.Ws + x;
+    o[0] = (((float)s0 / kh) / kw - 127.5f) * 0.0078125f;
+    o[(size_t)t.tot_px] = (((float)s1 / kh) / kw - 127.5f) * 0.0078125f;
+    o[2 * (size_t)t.tot_px] = (((float)s2 / kh) / kw - 127.5f) * 0.0078125f;
+  }
+}
+
 // --------------------------------------------------------------------------------------------- K2
 // mtcnn.py:39-41: conv1 3->10 (3x3) + PReLU, then MaxPool2d(2,2,ceil_mode=True); one thread per
 // pooled pixel, all 10 channels in registers.
@@ -495,23 +555,47 @@ __global__ void __launch_bounds__(256) crop_resize_kernel(const uint8_t* __restr
 // weights in their PyTorch layout read through L1/L2 (shared by every workgroup).
 __device__ __forceinline__ float prelu(float v, float a) { return v > 0.f ? v : v * a; }
 
-template <int CIN, int KS>
+// Register-tiled direct convolution: a thread computes COB output channels x PXB consecutive pixels,
+// so each LDS input value feeds COB*KS FMAs and each weight PXB FMAs.  wt is the layer's weight
+// transposed to [CIN][KS][KS][ldw] (output channel fastest), so the COB weights of one tap are one
+// or two 16-byte loads, identical across the lanes that share a channel block (L1 broadcast).
+// Per output the FMA order is (c, kh, kw), as in the reference's direct statement of the conv.
+template <int CIN, int KS, int COB, int PXB>
 __device__ void lds_conv_prelu(const float* __restrict__ in, int Hi, int Wi, float* __restrict__ out, int cout,
-                               const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ a) {
-  const int Ho = Hi - KS + 1, Wo = Wi - KS + 1, n = cout * Ho * Wo;
+                               const float* __restrict__ wt, int ldw, const float* __restrict__ b,
+                               const float* __restrict__ a) {
+  const int Ho = Hi - KS + 1, Wo = Wi - KS + 1;
+  const int xg = (Wo + PXB - 1) / PXB, per_cb = Ho * xg, n = (cout / COB) * per_cb;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int co = i / (Ho * Wo), p = i - co * (Ho * Wo), y = p / Wo, x = p - y * Wo;
-    float acc = b[co];
-    const float* wc = w + (size_t)co * CIN * KS * KS;
+    const int cb = i / per_cb, p = i - cb * per_cb, y = p / xg, x0 = (p - y * xg) * PXB;
+    float acc[COB][PXB];
+#pragma unroll
+    for (int co = 0; co < COB; ++co)
+#pragma unroll
+      for (int px = 0; px < PXB; ++px) acc[co][px] = b[cb * COB + co];
 #pragma unroll 1
     for (int c = 0; c < CIN; ++c) {
-      const float* ic = in + c * Hi * Wi + y * Wi + x;
 #pragma unroll
-      for (int kh = 0; kh < KS; ++kh)
+      for (int kh = 0; kh < KS; ++kh) {
+        const float* ir = in + c * Hi * Wi + (y + kh) * Wi + x0;
+        float v[PXB + KS - 1];
 #pragma unroll
-        for (int kw = 0; kw < KS; ++kw) acc = fmaf(ic[kh * Wi + kw], wc[(c * KS + kh) * KS + kw], acc);
+        for (int j = 0; j < PXB + KS - 1; ++j) v[j] = (x0 + j < Wi) ? ir[j] : 0.f;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+          const float* ww = wt + (size_t)((c * KS + kh) * KS + kw) * ldw + cb * COB;
+#pragma unroll
+          for (int co = 0; co < COB; ++co)
+#pragma unroll
+            for (int px = 0; px < PXB; ++px) acc[co][px] = fmaf(v[px + kw], ww[co], acc[co][px]);
+        }
+      }
     }
-    out[i] = prelu(acc, a[co]);
+#pragma unroll
+    for (int co = 0; co < COB; ++co)
+#pragma unroll
+      for (int px = 0; px < PXB; ++px)
+        if (x0 + px < Wo) out[(cb * COB + co) * Ho * Wo + y * Wo + x0 + px] = prelu(acc[co][px], a[cb * COB + co]);
   }
 }
 
@@ -562,19 +646,33 @@ __device__ void lds_maxpool_ceil(const float* __restrict__ in, int C, int Hi, in
   }
 }
 
-// dense layer on x.permute(0,3,2,1) flattened (mtcnn.py:93-94,150-151): feature f = (w*H + h)*C + c
-__device__ void lds_dense_permuted_prelu(const float* __restrict__ in, int C, int Hh, int Ww, float* __restrict__ out,
-                                         int nout, const float* __restrict__ w, const float* __restrict__ b,
+// dense layer on x.permute(0,3,2,1) flattened (mtcnn.py:93-94,150-151): feature f = (w*H + h)*C + c.
+// `feat` receives the permuted input (nin floats, LDS); wt is the weight transposed to [nin][nout]
+// so consecutive threads read consecutive outputs (coalesced).  With more threads than outputs the
+// reduction is split over KSPLIT thread groups and combined through `part` (LDS, KSPLIT*nout floats).
+__device__ void lds_dense_permuted_prelu(const float* __restrict__ in, int C, int Hh, int Ww, float* __restrict__ feat,
+                                         float* __restrict__ part, float* __restrict__ out, int nout,
+                                         const float* __restrict__ wt, const float* __restrict__ b,
                                          const float* __restrict__ a) {
   const int nin = C * Hh * Ww;
-  for (int o = threadIdx.x; o < nout; o += blockDim.x) {
-    float acc = b[o];
-    const float* wr = w + (size_t)o * nin;
-    for (int f = 0; f < nin; ++f) {
-      const int c = f % C, hw = f / C, h = hw % Hh, ww_ = hw / Hh;
-      acc = fmaf(in[c * Hh * Ww + h * Ww + ww_], wr[f], acc);
-    }
-    out[o] = prelu(acc, a[o]);
+  for (int f = threadIdx.x; f < nin; f += blockDim.x) {
+    const int c = f % C, hw = f / C, h = hw % Hh, w_ = hw / Hh;
+    feat[f] = in[c * Hh * Ww + h * Ww + w_];
+  }
+  __syncthreads();
+  const int ksplit = blockDim.x / nout;  // >= 1 (nout <= blockDim)
+  const int o = threadIdx.x % nout, g = threadIdx.x / nout;
+  if (g < ksplit) {
+    const int f0 = (nin * g) / ksplit, f1 = (nin * (g + 1)) / ksplit;
+    float acc = 0.f;
+    for (int f = f0; f < f1; ++f) acc = fmaf(feat[f], wt[(size_t)f * nout + o], acc);
+    part[g * nout + o] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < nout) {
+    float acc = b[threadIdx.x];
+    for (int g2 = 0; g2 < ksplit; ++g2) acc += part[g2 * nout + threadIdx.x];
+    out[threadIdx.x] = prelu(acc, a[threadIdx.x]);
   }
 }
 
@@ -597,17 +695,17 @@ __global__ void __launch_bounds__(256) rnet_kernel(const float* __restrict__ cro
   const float* src = crops + ((size_t)img * KEEP + k) * 3 * 24 * 24;
   for (int i = threadIdx.x; i < 1728; i += blockDim.x) Bf[i] = src[i];
   __syncthreads();
-  lds_conv_prelu<3, 3>(Bf, 24, 24, A, 28, w.c1w, w.c1b, w.a1);            // 28 x 22 x 22
+  lds_conv_prelu<3, 3, 4, 2>(Bf, 24, 24, A, 28, w.c1w, 28, w.c1b, w.a1);   // 28 x 22 x 22
   __syncthreads();
   lds_maxpool_ceil<3>(A, 28, 22, 22, Bf);                                  // 28 x 11 x 11
   __syncthreads();
-  lds_conv_prelu<28, 3>(Bf, 11, 11, A, 48, w.c2w, w.c2b, w.a2);            // 48 x 9 x 9
+  lds_conv_prelu<28, 3, 4, 3>(Bf, 11, 11, A, 48, w.c2w, 48, w.c2b, w.a2);  // 48 x 9 x 9
   __syncthreads();
   lds_maxpool_ceil<3>(A, 48, 9, 9, Bf);                                    // 48 x 4 x 4
   __syncthreads();
-  lds_conv_prelu<48, 2>(Bf, 4, 4, A, 64, w.c3w, w.c3b, w.a3);              // 64 x 3 x 3
+  lds_conv_prelu<48, 2, 4, 1>(Bf, 4, 4, A, 64, w.c3w, 64, w.c3b, w.a3);    // 64 x 3 x 3
   __syncthreads();
-  lds_dense_permuted_prelu(A, 64, 3, 3, Bf, 128, w.d4w, w.d4b, w.a4);
+  lds_dense_permuted_prelu(A, 64, 3, 3, A + 1024, A + 2048, Bf, 128, w.d4w, w.d4b, w.a4);
   __syncthreads();
   if (threadIdx.x < 6) {
     const int o = threadIdx.x;
@@ -641,18 +739,18 @@ __global__ void __launch_bounds__(512) onet_kernel(const float* __restrict__ cro
   lds_conv_prelu_pool<3, 3, 3>(Y, 48, 48, X, 32, w.c1w, w.c1b, w.a1);     // conv 46x46 -> pool 23x23
   __syncthreads();
   for (int half = 0; half < 2; ++half) {  // conv2 in two 32-channel halves: the full 64x21x21 map would not fit LDS
-    lds_conv_prelu<32, 3>(X, 23, 23, Y, 32, w.c2w + (size_t)half * 32 * 32 * 9, w.c2b + half * 32, w.a2 + half * 32);
+    lds_conv_prelu<32, 3, 8, 4>(X, 23, 23, Y, 32, w.c2w + half * 32, 64, w.c2b + half * 32, w.a2 + half * 32);
     __syncthreads();
     lds_maxpool_ceil<3>(Y, 32, 21, 21, Z + half * 32 * 100);              // -> 64 x 10 x 10
     __syncthreads();
   }
-  lds_conv_prelu<64, 3>(Z, 10, 10, Y, 64, w.c3w, w.c3b, w.a3);            // 64 x 8 x 8
+  lds_conv_prelu<64, 3, 4, 2>(Z, 10, 10, Y, 64, w.c3w, 64, w.c3b, w.a3);  // 64 x 8 x 8
   __syncthreads();
   lds_maxpool_ceil<2>(Y, 64, 8, 8, X);                                     // 64 x 4 x 4
   __syncthreads();
-  lds_conv_prelu<64, 2>(X, 4, 4, Y, 128, w.c4w, w.c4b, w.a4);             // 128 x 3 x 3
+  lds_conv_prelu<64, 2, 4, 1>(X, 4, 4, Y, 128, w.c4w, 128, w.c4b, w.a4);  // 128 x 3 x 3
   __syncthreads();
-  lds_dense_permuted_prelu(Y, 128, 3, 3, X, 256, w.d5w, w.d5b, w.a5);
+  lds_dense_permuted_prelu(Y, 128, 3, 3, Z, Z + 1152, X, 256, w.d5w, w.d5b, w.a5);
   __syncthreads();
   if (threadIdx.x < 16) {
     const int o = threadIdx.x;
@@ -893,8 +991,9 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
       GETW(d4, wr, "dense4.weight", 73728) GETW(d4b, wr, "dense4.bias", 128) GETW(a4, wr, "prelu4.weight", 128)
       GETW(d51, wr, "dense5_1.weight", 256) GETW(d51b, wr, "dense5_1.bias", 2)
       GETW(d52, wr, "dense5_2.weight", 512) GETW(d52b, wr, "dense5_2.bias", 4)
-      m->rw = RNetW{UP(c1, 756), UP(b1, 28), UP(a1, 28), UP(c2, 12096), UP(b2, 48), UP(a2, 48), UP(c3, 12288), UP(b3, 64),
-                    UP(a3, 64), UP(d4, 73728), UP(d4b, 128), UP(a4, 128), UP(d51, 256), UP(d51b, 2), UP(d52, 512), UP(d52b, 4)};
+      m->rw = RNetW{up_transposed(*m, c1, 28, 3, 3), UP(b1, 28), UP(a1, 28), up_transposed(*m, c2, 48, 28, 3), UP(b2, 48),
+                    UP(a2, 48), up_transposed(*m, c3, 64, 48, 2), UP(b3, 64), UP(a3, 64), up_transposed(*m, d4, 128, 576, 1),
+                    UP(d4b, 128), UP(a4, 128), UP(d51, 256), UP(d51b, 2), UP(d52, 512), UP(d52b, 4)};
     }
     {
       GETW(c1, wo, "conv1.weight", 864) GETW(b1, wo, "conv1.bias", 32) GETW(a1, wo, "prelu1.weight", 32)
@@ -905,8 +1004,9 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
       GETW(d61, wo, "dense6_1.weight", 512) GETW(d61b, wo, "dense6_1.bias", 2)
       GETW(d62, wo, "dense6_2.weight", 1024) GETW(d62b, wo, "dense6_2.bias", 4)
       GETW(d63, wo, "dense6_3.weight", 2560) GETW(d63b, wo, "dense6_3.bias", 10)
-      m->ow = ONetW{UP(c1, 864), UP(b1, 32), UP(a1, 32), UP(c2, 18432), UP(b2, 64), UP(a2, 64), UP(c3, 36864), UP(b3, 64),
-                    UP(a3, 64), UP(c4, 32768), UP(b4, 128), UP(a4, 128), UP(d5, 294912), UP(d5b, 256), UP(a5, 256),
+      m->ow = ONetW{UP(c1, 864), UP(b1, 32), UP(a1, 32), up_transposed(*m, c2, 64, 32, 3), UP(b2, 64), UP(a2, 64),
+                    up_transposed(*m, c3, 64, 64, 3), UP(b3, 64), UP(a3, 64), up_transposed(*m, c4, 128, 64, 2), UP(b4, 128),
+                    UP(a4, 128), up_transposed(*m, d5, 256, 1152, 1), UP(d5b, 256), UP(a5, 256),
                     UP(d61, 512), UP(d61b, 2), UP(d62, 1024), UP(d62b, 4), UP(d63, 2560), UP(d63b, 10)};
     }
     const int B = cfg->max_batch;
@@ -980,7 +1080,17 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   const int B = b;
   const size_t nseg = (size_t)MAX_LEVELS * cfg.max_batch;
   VNF_HIP(hipMemsetAsync(m->cand_cnt, 0, (nseg * 2 + (size_t)cfg.max_batch * 3 + 16) * 4, s));
-  hipLaunchKernelGGL(pyramid_kernel, dim3((t.tot_px + 255) / 256, B), dim3(256), 0, s, frames, H, W, t, m->lvl);
+  {
+    // bin sums must stay exact in fp32 (< 2^24): always true below 256x256-pixel bins
+    const bool fast = (W * 3) % 16 == 0 && (size_t)W * 12 <= 64 * 1024 && ((reinterpret_cast<uintptr_t>(frames)) & 15) == 0;
+    if (fast) {
+      int rows = 0;
+      for (int l = 0; l < t.n; ++l) rows += t.l[l].Hs;
+      hipLaunchKernelGGL(pyramid_rows_kernel, dim3(rows, B), dim3(256), (size_t)W * 12, s, frames, H, W, t, m->lvl);
+    } else {
+      hipLaunchKernelGGL(pyramid_kernel, dim3((t.tot_px + 255) / 256, B), dim3(256), 0, s, frames, H, W, t, m->lvl);
+    }
+  }
   hipLaunchKernelGGL(pnet_conv1_pool_kernel, dim3((t.tot_p1 + 255) / 256, B), dim3(256), 0, s, m->lvl, t, m->pw, m->p1);
   hipLaunchKernelGGL(pnet_conv2_kernel, dim3((t.tot_c2 + 255) / 256, B), dim3(256), 0, s, m->p1, t, m->pw, m->c2);
   hipLaunchKernelGGL(pnet_conv3_heads_kernel, dim3((t.tot_out + 255) / 256, B), dim3(256), 0, s, m->c2, t, m->pw,
