@@ -62,14 +62,112 @@ def cpu_baseline(budget_s=12.0):
             "sample": "%d images (batches of %d of the bs=256 workload), fp32 torch-CPU oracle, %.1f s" % (n, bs, dt)}
 
 
+def cpu_baseline_pipeline(frames, template_size=160, n_frames=32, budget_s=12.0):
+    """Oracle detect -> align -> embed -> classify on a bounded sample of the same frames."""
+    import numpy as np
+    import torch
+    from oracle import align as oalign, irv1, mlp as omlp, mtcnn as om
+    from vn_celeb_face_recognition_amd.weights import generate_state_dict
+    torch.set_num_threads(host_cores())
+    d = os.path.join(REPO, "vn_celeb_face_recognition_amd", "weights_mtcnn")
+    p, r, o = (torch.load(os.path.join(d, n + ".pt"), weights_only=True) for n in ("pnet", "rnet", "onet"))
+    sd, msd = generate_state_dict("irv1", 0, as_torch=True), generate_state_dict("mlp", 0, as_torch=True)
+    tmpl = oalign.CENTER_POINTS["(%d, %d)" % (template_size, template_size)]
+    faces = 0
+    t0 = time.perf_counter()
+    for f in frames[:n_frames]:
+        boxes, _, points = om.mtcnn_detect([f], p, r, o, min_face_size=50, ties="table")
+        crops = oalign.detect_align_faces(f, boxes[0], points[0], tmpl, template_size, template_size)
+        if crops:
+            x = torch.from_numpy(np.stack([oalign.transforms_default(c) for c in crops]))
+            omlp.mlp_forward(msd, irv1.irv1_forward(sd, x))
+        faces += len(crops)
+        n_done = n_done + 1 if "n_done" in dir() else 1
+        if time.perf_counter() - t0 >= budget_s:
+            break
+    n_frames = n_done
+    dt = time.perf_counter() - t0
+    return {"value": round(faces / dt, 2), "unit": "faces/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d of the synthetic 1080p frames (%d faces), oracle detect+align+embed+classify, %.1f s" % (n_frames, faces, dt)}
+
+
+def run_pipeline(args):
+    """--workload pipeline: BASELINE.json configs[2]/[3] -- faces/sec end to end (detect + align + embed +
+    classify) on synthetic 1080p frames, 16 frames per step per GPU, frames resident in HBM."""
+    import torch
+    import torch.distributed as dist
+    from vn_celeb_face_recognition_amd import dist as vdist, models
+    from vn_celeb_face_recognition_amd.pipeline import FacePipeline
+    from vn_celeb_face_recognition_amd.synth import make_frames
+    rank, world, local = vdist.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    NF, PER = 16, 8
+    frames, truth = make_frames(NF * 2, PER, seed=rank)
+    det = models.MTCNN(keep_all=True, min_face_size=50, device=dev, max_batch=NF, max_height=1080, max_width=1920)
+    enc = models.InceptionResnetV1(pretrained=None, compute_dtype=args.dtype, max_batch=256).to(dev).eval()
+    clf = models.MLPModel(512, 1001).to(dev).eval()
+    pipe = FacePipeline(det, enc, clf, {"label": list(range(1001)), "name": ["c%d" % i for i in range(1001)]}, 160, 0.0)
+    batches = [torch.from_numpy(frames[i * NF:(i + 1) * NF]).to(dev) for i in range(2)]
+
+    def step(i):
+        counts, boxes, emb = pipe.embed_frames(batches[i & 1])
+        clf.classify(emb, want_logp=False)
+        if world > 1:
+            vdist.all_gather_embeddings(emb)
+        return sum(counts)
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    faces = 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        faces += step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    tot = torch.tensor([wall, float(faces)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); wall = float(mx[0])
+        dist.all_reduce(tot); faces = int(tot[1].item())
+    if rank == 0:
+        stage1_bytes = 13_316_400.0 * NF      # SURVEY.md 8(d): stage-1 algorithmic bytes per 1080p frame, min_face 50
+        achieved = stage1_bytes * args.steps / wall / 1e9
+        out = {"metric": "faces/sec end-to-end (detect+embed+classify) on 1080p frames", "value": round(faces / wall, 1),
+               "unit": "faces/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[2]+[3]: MTCNN detect + align + IRv1 embed + MLP classify, "
+                                      "synthetic 1080p frames, %d frames/step/GPU, %d pasted faces/frame" % (NF, PER),
+                          "frames_per_s": round(world * NF * args.steps / wall, 1), "min_face_size": 50},
+               "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                            "frac": round(achieved / 8000.0, 5), "traffic": None,
+                            "kernel": "whole step priced on stage-1 (pyramid + P-Net) algorithmic bytes only: a lower bound"}}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_pipeline(frames)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="embed", choices=["embed", "pipeline"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.workload == "pipeline":
+        return run_pipeline(args)
 
     import torch
     import torch.distributed as dist
