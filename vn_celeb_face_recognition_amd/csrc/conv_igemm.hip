@@ -143,13 +143,6 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, f32x4_t (&acc)[BM 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, frow = lane & 15, fgrp = lane >> 4;
   const int HoWo = a.Ho * a.Wo;
-  int sg = 0;
-#pragma unroll
-  for (int s = 1; s < 4; ++s)
-    if (s < a.nseg && n0 >= a.seg_c0[s]) sg = s;
-  char* const dptr = a.seg_ptr[sg];
-  const int dld = a.seg_ld[sg], dc0 = a.seg_c0[sg];
-
   float* sC = reinterpret_cast<float*>(smem);
   constexpr int CST = BN + 4;  // floats per staged row (+16 B pad: conflict-free float4 writes)
   constexpr int CPR = BN / 8;  // 8-channel chunks per row
@@ -165,6 +158,14 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, f32x4_t (&acc)[BM 
   const int c = n0 + cc * 8;
   const bool cok = c < a.Cout;
   const int cl = cok ? c : 0;  // in-range column for the loads of masked threads
+  // destination tensor of this thread's 8-channel chunk (segment boundaries are multiples of 8, so a
+  // tile may span several destinations: concat-free routing happens per chunk, not per tile)
+  int sg = 0;
+#pragma unroll
+  for (int s = 1; s < 4; ++s)
+    if (s < a.nseg && c >= a.seg_c0[s]) sg = s;
+  char* const dptr = a.seg_ptr[sg];
+  const int dld = a.seg_ld[sg], dc0 = a.seg_c0[sg];
   f32x4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
   float slope[8];
   if (a.ncls == 1) {
@@ -495,6 +496,12 @@ static const TileCfg kCfgs[] = {
     // 8-wave workgroups: two waves per SIMD, so one wave's DMA issue / LDS reads hide under the other's MFMAs
     {128, 128, 2, 4, 3}, {256, 128, 4, 2, 3}, {256, 64, 4, 2, 3}, {128, 64, 4, 2, 3}, {128, 256, 2, 4, 3},
     {128, 128, 2, 4, 4},
+    // deep rings for problems with about one workgroup per CU: the K loop is a serial chain of
+    // L2 / Infinity-Cache round trips, so more tiles in flight shorten it directly
+    {128, 64, 4, 2, 6},  {64, 64, 2, 2, 8},   {64, 32, 2, 2, 8},  {32, 64, 2, 2, 8},  {128, 32, 4, 1, 6},
+    {64, 128, 2, 4, 5},  {128, 64, 2, 2, 6},
+    // whole-N tiles: the activation operand (which comes from beyond L2) is read exactly once
+    {64, 256, 1, 8, 3},  {64, 256, 1, 8, 4},  {128, 256, 2, 4, 3},
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -505,8 +512,6 @@ static bool dma_capable(const ConvArgs& a) { return (a.Kpad / (128 / dtype_size(
 bool conv_cfg_ok(const ConvArgs& a, int cfg) {
   if (cfg < 0 || cfg >= kNumCfgs || !dma_capable(a)) return false;
   const TileCfg& c = kCfgs[cfg];
-  for (int i = 0; i < a.nseg; ++i)
-    if (a.seg[i].c0 % c.bn) return false;  // a tile must map to exactly one destination tensor
   if (c.bn > 32 && a.Cout <= c.bn / 2) return false;  // more than half the tile would be padding
   if (a.cout_pad % c.bn) return false;                // weight rows n0..n0+BN-1 must exist in the packed buffer
   const int lds = c.s * (c.bm + c.bn) * 128 + (a.Kpad / (128 / dtype_size(a.dtype))) * 8 * 16;
@@ -535,6 +540,16 @@ static hipError_t launch_cfg(int cfg, const KArgs& k, hipStream_t s) {
     case 16: return launch_dma<T, 128, 64, 4, 2, 3>(k, s);
     case 17: return launch_dma<T, 128, 256, 2, 4, 3>(k, s);
     case 18: return launch_dma<T, 128, 128, 2, 4, 4>(k, s);
+    case 19: return launch_dma<T, 128, 64, 4, 2, 6>(k, s);
+    case 20: return launch_dma<T, 64, 64, 2, 2, 8>(k, s);
+    case 21: return launch_dma<T, 64, 32, 2, 2, 8>(k, s);
+    case 22: return launch_dma<T, 32, 64, 2, 2, 8>(k, s);
+    case 23: return launch_dma<T, 128, 32, 4, 1, 6>(k, s);
+    case 24: return launch_dma<T, 64, 128, 2, 4, 5>(k, s);
+    case 25: return launch_dma<T, 128, 64, 2, 2, 6>(k, s);
+    case 26: return launch_dma<T, 64, 256, 1, 8, 3>(k, s);
+    case 27: return launch_dma<T, 64, 256, 1, 8, 4>(k, s);
+    case 28: return launch_dma<T, 128, 256, 2, 4, 3>(k, s);
   }
   return hipErrorInvalidValue;
 }
@@ -544,11 +559,7 @@ static hipError_t launch_typed(const ConvArgs& a, const KArgs& k, hipStream_t s)
   static const int env_reg = getenv("VNF_CONV_REG") ? atoi(getenv("VNF_CONV_REG")) : 0;
   if (a.cfg >= 0 && !env_reg && k.zero && conv_cfg_ok(a, a.cfg)) return launch_cfg<T>(a.cfg, k, s);
   // heuristic: BN must divide every segment boundary; keep ~2 workgroups per CU when possible
-  auto fits = [&](int b) {
-    for (int i = 0; i < a.nseg; ++i)
-      if (a.seg[i].c0 % b) return false;
-    return true;
-  };
+  auto fits = [&](int) { return true; };
   int bn = 128;
   while (bn > 32 && !(fits(bn) && (a.Cout % bn == 0 || a.Cout > 2 * bn))) bn >>= 1;
   if (!fits(bn)) return hipErrorInvalidValue;

@@ -92,6 +92,9 @@ struct Encoder : HandleBase {
   int autotune();
   ConvArgs conv_args(const ConvLayer& L, int n0, int nn) const;
   int run(const void* x, int n, int x_dtype, float* out, hipStream_t s, std::string* report = nullptr);
+  int run_range(const void* x, int i0, int i1, int x_dtype, float* out, hipStream_t s, std::string* report);
+  hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t join_ev[4] = {nullptr, nullptr, nullptr, nullptr}, fork_ev = nullptr;
 };
 
 int build_irv1(Encoder& e, WeightMap& wm);
