@@ -230,6 +230,11 @@ def main():
         achieved = flop_per_step / (dev_ms / args.steps * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype != "f32" else 157.3
         alg, executed = model.flops_per_image()
+        traffic = None   # HBM bytes per step from rocprofv3 PMC passes (collected separately, profiles/)
+        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
+        if args.dtype == "bf16" and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_step")
         out = {
             "metric": "embeddings/sec @ bs=256 (InceptionResnetV1, 160x160)",
             "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps,
@@ -240,8 +245,10 @@ def main():
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "parallelism": "dp%d (frames sharded, all-gather of embeddings)" % world},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
-                         "kernel": "conv_igemm_kernel (all launches of one embed step; device time by HIP events)",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "traffic_note": "HBM bytes per step, FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE from separate "
+                                         "rocprofv3 --pmc passes (profiles/r01_traffic.json); algorithmic floor 87 MB",
+                         "kernel": "conv_igemm_dma_kernel (all launches of one embed step; device time by HIP events)",
                          "flop_per_step_algorithmic": flop_per_step,
                          "flop_per_image_executed": executed, "flop_per_image_counted_by_engine": alg,
                          "device_ms_per_step": round(dev_ms / args.steps, 4)},
