@@ -150,86 +150,144 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, f32x4_t (&acc)[BM 
   constexpr int EPASS = (BM * CST * 4 <= LDS_BYTES) ? 1 : WM;
   constexpr int RPP = BM / EPASS;
   static_assert(RPP * CST * 4 <= LDS_BYTES, "epilogue staging does not fit");
-  // Each thread owns ONE 8-channel column chunk and NIT rows per pass (compile-time trip count), so
-  // the bias is loaded once and every residual load of a pass is in flight before the barrier.
-  constexpr int NIT = RPP * CPR / NT, RSTEP = NT / CPR;
-  static_assert(RPP * CPR % NT == 0 && NT % CPR == 0, "epilogue thread map");
-  const int cc = tid % CPR, r0 = tid / CPR;
-  const int c = n0 + cc * 8;
-  const bool cok = c < a.Cout;
-  const int cl = cok ? c : 0;  // in-range column for the loads of masked threads
-  // destination tensor of this thread's 8-channel chunk (segment boundaries are multiples of 8, so a
-  // tile may span several destinations: concat-free routing happens per chunk, not per tile)
-  int sg = 0;
+  // Thread map of the store phase.  When the chunk count per row divides the thread count every
+  // thread owns ONE 8-channel column chunk (bias loaded once, residual loads hoisted above the
+  // barrier); tiles whose width is not a power of two (96, 192 channels) use the general map.
+  constexpr bool FIXEDCOL = (NT % CPR == 0) && ((RPP * CPR) % NT == 0);
+  constexpr int NIT = (RPP * CPR + NT - 1) / NT, RSTEP = NT / CPR;
+  if constexpr (FIXEDCOL) {
+    const int cc = tid % CPR, r0 = tid / CPR;
+    const int c = n0 + cc * 8;
+    const bool cok = c < a.Cout;
+    const int cl = cok ? c : 0;  // in-range column for the loads of masked threads
+    // destination tensor of this thread's 8-channel chunk (segment boundaries are multiples of 8, so a
+    // tile may span several destinations: concat-free routing happens per chunk, not per tile)
+    int sg = 0;
 #pragma unroll
-  for (int s = 1; s < 4; ++s)
-    if (s < a.nseg && c >= a.seg_c0[s]) sg = s;
-  char* const dptr = a.seg_ptr[sg];
-  const int dld = a.seg_ld[sg], dc0 = a.seg_c0[sg];
-  f32x4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-  float slope[8];
-  if (a.ncls == 1) {
-    b0 = *reinterpret_cast<const f32x4_t*>(a.bias + cl);
-    b1 = *reinterpret_cast<const f32x4_t*>(a.bias + cl + 4);
-  }
-  if (a.act == ACT_PRELU) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) slope[e] = a.slope[cl + e];
-  }
-  for (int pass = 0; pass < EPASS; ++pass) {
-    float rv[NIT][8];
-    if (a.res) {
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int m = min(m0 + pass * RPP + r0 + it * RSTEP, a.M - 1);
-        load8<T>(a.res + ((size_t)m * a.ldres + cl) * ES, rv[it]);
-      }
+    for (int s = 1; s < 4; ++s)
+      if (s < a.nseg && c >= a.seg_c0[s]) sg = s;
+    char* const dptr = a.seg_ptr[sg];
+    const int dld = a.seg_ld[sg], dc0 = a.seg_c0[sg];
+    f32x4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    float slope[8];
+    if (a.ncls == 1) {
+      b0 = *reinterpret_cast<const f32x4_t*>(a.bias + cl);
+      b1 = *reinterpret_cast<const f32x4_t*>(a.bias + cl + 4);
     }
-    if ((wm * WTM) / RPP == pass) {
-      const int rbase = wm * WTM - pass * RPP;
+    if (a.act == ACT_PRELU) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          *reinterpret_cast<f32x4_t*>(sC + (rbase + i * 16 + frow) * CST + wn * WTN + j * 16 + fgrp * 4) = acc[i][j];
+      for (int e = 0; e < 8; ++e) slope[e] = a.slope[cl + e];
     }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int r = r0 + it * RSTEP;
-      const int m = m0 + pass * RPP + r;
-      float v[8];
-      const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(sC + r * CST + cc * 8);
-      const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(sC + r * CST + cc * 8 + 4);
-      if (a.ncls == 9) {
-        const int mm = min(m, a.M - 1);
-        const int rr = mm % HoWo, ho = rr / a.Wo, wo = rr - ho * a.Wo;
-        const int cls = (ho == 0 ? 0 : (ho == a.Ho - 1 ? 2 : 1)) * 3 + (wo == 0 ? 0 : (wo == a.Wo - 1 ? 2 : 1));
-        const float* bp = a.bias + (size_t)cls * a.cout_pad + cl;
-        b0 = *reinterpret_cast<const f32x4_t*>(bp);
-        b1 = *reinterpret_cast<const f32x4_t*>(bp + 4);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = v0[e] + b0[e]; v[4 + e] = v1[e] + b1[e]; }
+    for (int pass = 0; pass < EPASS; ++pass) {
+      float rv[NIT][8];
       if (a.res) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rv[it][e];
+        for (int it = 0; it < NIT; ++it) {
+          const int m = min(m0 + pass * RPP + r0 + it * RSTEP, a.M - 1);
+          load8<T>(a.res + ((size_t)m * a.ldres + cl) * ES, rv[it]);
+        }
       }
-      if (a.act == ACT_RELU) {
+      if ((wm * WTM) / RPP == pass) {
+        const int rbase = wm * WTM - pass * RPP;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      } else if (a.act == ACT_PRELU) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope[e];
+          for (int j = 0; j < TN; ++j)
+            *reinterpret_cast<f32x4_t*>(sC + (rbase + i * 16 + frow) * CST + wn * WTN + j * 16 + fgrp * 4) = acc[i][j];
       }
-      if (m < a.M && cok) {
-        if (a.out_f32)
-          store8<float>(dptr + ((size_t)m * dld + (c - dc0)) * 4, v);
-        else
-          store8<T>(dptr + ((size_t)m * dld + (c - dc0)) * ES, v);
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int r = r0 + it * RSTEP;
+        const int m = m0 + pass * RPP + r;
+        float v[8];
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(sC + r * CST + cc * 8);
+        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(sC + r * CST + cc * 8 + 4);
+        if (a.ncls == 9) {
+          const int mm = min(m, a.M - 1);
+          const int rr = mm % HoWo, ho = rr / a.Wo, wo = rr - ho * a.Wo;
+          const int cls = (ho == 0 ? 0 : (ho == a.Ho - 1 ? 2 : 1)) * 3 + (wo == 0 ? 0 : (wo == a.Wo - 1 ? 2 : 1));
+          const float* bp = a.bias + (size_t)cls * a.cout_pad + cl;
+          b0 = *reinterpret_cast<const f32x4_t*>(bp);
+          b1 = *reinterpret_cast<const f32x4_t*>(bp + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = v0[e] + b0[e]; v[4 + e] = v1[e] + b1[e]; }
+        if (a.res) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[it][e];
+        }
+        if (a.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (a.act == ACT_PRELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope[e];
+        }
+        if (m < a.M && cok) {
+          if (a.out_f32)
+            store8<float>(dptr + ((size_t)m * dld + (c - dc0)) * 4, v);
+          else
+            store8<T>(dptr + ((size_t)m * dld + (c - dc0)) * ES, v);
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
+  } else {
+    for (int pass = 0; pass < EPASS; ++pass) {
+      if ((wm * WTM) / RPP == pass) {
+        const int rbase = wm * WTM - pass * RPP;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            *reinterpret_cast<f32x4_t*>(sC + (rbase + i * 16 + frow) * CST + wn * WTN + j * 16 + fgrp * 4) = acc[i][j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NT;
+        const int r = idx / CPR, cc = idx - r * CPR;
+        const int m = m0 + pass * RPP + r, c = n0 + cc * 8;
+        if (idx < RPP * CPR && m < a.M && c < a.Cout) {
+          int sg = 0;
+#pragma unroll
+          for (int s = 1; s < 4; ++s)
+            if (s < a.nseg && c >= a.seg_c0[s]) sg = s;
+          float v[8];
+          const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(sC + r * CST + cc * 8);
+          const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(sC + r * CST + cc * 8 + 4);
+          int cls = 0;
+          if (a.ncls == 9) {
+            const int rr = m % HoWo, ho = rr / a.Wo, wo = rr - ho * a.Wo;
+            cls = (ho == 0 ? 0 : (ho == a.Ho - 1 ? 2 : 1)) * 3 + (wo == 0 ? 0 : (wo == a.Wo - 1 ? 2 : 1));
+          }
+          const float* bp = a.bias + (size_t)cls * a.cout_pad + c;
+          const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bp), b1 = *reinterpret_cast<const f32x4_t*>(bp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = v0[e] + b0[e]; v[4 + e] = v1[e] + b1[e]; }
+          if (a.res) {
+            float rv[8];
+            load8<T>(a.res + ((size_t)m * a.ldres + c) * ES, rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          }
+          if (a.act == ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (a.act == ACT_PRELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope[c + e];
+          }
+          char* const dptr = a.seg_ptr[sg];
+          if (a.out_f32)
+            store8<float>(dptr + ((size_t)m * a.seg_ld[sg] + (c - a.seg_c0[sg])) * 4, v);
+          else
+            store8<T>(dptr + ((size_t)m * a.seg_ld[sg] + (c - a.seg_c0[sg])) * ES, v);
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -502,6 +560,10 @@ static const TileCfg kCfgs[] = {
     {64, 128, 2, 4, 5},  {128, 64, 2, 2, 6},
     // whole-N tiles: the activation operand (which comes from beyond L2) is read exactly once
     {64, 256, 1, 8, 3},  {64, 256, 1, 8, 4},  {128, 256, 2, 4, 3},
+    // 96- and 192-channel tiles: the inception widths, so one tile spans the whole N and the gathered
+    // activation operand crosses the L2 -> LDS path once per tap instead of once per tap and N tile
+    {128, 96, 4, 1, 3},  {64, 96, 2, 2, 4},   {128, 192, 2, 4, 3}, {64, 192, 2, 4, 3},  {256, 96, 4, 1, 3},
+    {64, 192, 2, 4, 4},
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -513,7 +575,8 @@ bool conv_cfg_ok(const ConvArgs& a, int cfg) {
   if (cfg < 0 || cfg >= kNumCfgs || !dma_capable(a)) return false;
   const TileCfg& c = kCfgs[cfg];
   if (c.bn > 32 && a.Cout <= c.bn / 2) return false;  // more than half the tile would be padding
-  if (a.cout_pad % c.bn) return false;                // weight rows n0..n0+BN-1 must exist in the packed buffer
+  if (((a.Cout + c.bn - 1) / c.bn) * c.bn > a.cout_pad) return false;  // weight rows n0..n0+BN-1 must exist in the packed buffer
+  if ((c.bn % 64) && a.Cout % c.bn) return false;      // 96/192-wide tiles only where they divide N
   const int lds = c.s * (c.bm + c.bn) * 128 + (a.Kpad / (128 / dtype_size(a.dtype))) * 8 * 16;
   return lds <= 160 * 1024;
 }
@@ -550,6 +613,12 @@ static hipError_t launch_cfg(int cfg, const KArgs& k, hipStream_t s) {
     case 26: return launch_dma<T, 64, 256, 1, 8, 3>(k, s);
     case 27: return launch_dma<T, 64, 256, 1, 8, 4>(k, s);
     case 28: return launch_dma<T, 128, 256, 2, 4, 3>(k, s);
+    case 29: return launch_dma<T, 128, 96, 4, 1, 3>(k, s);
+    case 30: return launch_dma<T, 64, 96, 2, 2, 4>(k, s);
+    case 31: return launch_dma<T, 128, 192, 2, 4, 3>(k, s);
+    case 32: return launch_dma<T, 64, 192, 2, 4, 3>(k, s);
+    case 33: return launch_dma<T, 256, 96, 4, 1, 3>(k, s);
+    case 34: return launch_dma<T, 64, 192, 2, 4, 4>(k, s);
   }
   return hipErrorInvalidValue;
 }

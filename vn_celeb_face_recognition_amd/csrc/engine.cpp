@@ -155,6 +155,11 @@ int Encoder::autotune() {
         if (ms < best) { best = ms; best_cfg = cfg; }
       }
       L.cfg = best_cfg;
+      static const int force = getenv("VNF_FORCE_CFG") ? atoi(getenv("VNF_FORCE_CFG")) : -2;
+      if (force >= -1) {
+        ConvArgs a = conv_args(L, 0, nn);
+        if (force == -1 || conv_cfg_ok(a, force)) L.cfg = force;
+      }
     }
   }
   (void)hipEventDestroy(e0);
