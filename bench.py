@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--model", default="irv1", choices=["irv1", "ir100"],
+                    help="irv1 = BASELINE configs[1] (default); ir100 = configs[4], the ArcFace IR-100 swap-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.workload == "pipeline":
@@ -172,8 +174,8 @@ def main():
     import torch
     import torch.distributed as dist
     from vn_celeb_face_recognition_amd import dist as vdist
-    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
-    from vn_celeb_face_recognition_amd.weights import IRV1_MACS_PER_IMAGE
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1, iresnet100
+    from vn_celeb_face_recognition_amd.weights import IR100_MACS_PER_IMAGE, IRV1_MACS_PER_IMAGE
 
     rank, world, local = vdist.init_from_env("nccl")
     if world != args.gpus:
@@ -182,9 +184,14 @@ def main():
     dev = torch.device("cuda", local)
 
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
-    model = InceptionResnetV1(pretrained=None, device=dev, compute_dtype=args.dtype, max_batch=BATCH).eval()
+    if args.model == "irv1":
+        model = InceptionResnetV1(pretrained=None, device=dev, compute_dtype=args.dtype, max_batch=BATCH).eval()
+        size, macs, mname = 160, IRV1_MACS_PER_IMAGE, "InceptionResnetV1"
+    else:
+        model = iresnet100(pretrained=False, compute_dtype=args.dtype, max_batch=BATCH).to(dev).eval()
+        size, macs, mname = 112, IR100_MACS_PER_IMAGE, "IResNet-100"
     g = torch.Generator().manual_seed(rank)
-    x = torch.randn((BATCH, 3, 160, 160), generator=g).to(dev).to(tdt)
+    x = torch.randn((BATCH, 3, size, size), generator=g).to(dev).to(tdt)
     gathered = [torch.empty((world * BATCH, 512), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
 
     def step(i, pending):
@@ -226,22 +233,22 @@ def main():
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         value = world * BATCH * args.steps / wall
-        flop_per_step = 2.0 * IRV1_MACS_PER_IMAGE * BATCH          # 2.8353 GFLOP / image
+        flop_per_step = 2.0 * macs * BATCH          # 2.8353 (IRv1) / 24.179 (IR-100) GFLOP per image
         achieved = flop_per_step / (dev_ms / args.steps * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype != "f32" else 157.3
         alg, executed = model.flops_per_image()
         traffic = None   # HBM bytes per step from rocprofv3 PMC passes (collected separately, profiles/)
         tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
-        if args.dtype == "bf16" and os.path.exists(tpath):
+        if args.dtype == "bf16" and args.model == "irv1" and os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_step")
         out = {
-            "metric": "embeddings/sec @ bs=256 (InceptionResnetV1, 160x160)",
+            "metric": "embeddings/sec @ bs=256 (%s, %dx%d)" % (mname, size, size),
             "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: InceptionResnetV1 embedding only, synthetic 160x160 %s, "
-                                   "bs=256 per GPU, generator weights seed 0" % args.dtype,
+            "config": {"workload": "BASELINE.json configs[%d]: %s embedding only, synthetic %dx%d %s, "
+                                   "bs=256 per GPU, generator weights seed 0" % (1 if args.model == "irv1" else 4, mname, size, size, args.dtype),
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "parallelism": "dp%d (frames sharded, all-gather of embeddings)" % world},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -253,7 +260,7 @@ def main():
                          "flop_per_image_executed": executed, "flop_per_image_counted_by_engine": alg,
                          "device_ms_per_step": round(dev_ms / args.steps, 4)},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.model == "irv1":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
