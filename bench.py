@@ -56,7 +56,7 @@ def cpu_baseline(budget_s=12.0):
         irv1.irv1_forward(sd, x)
         n += bs
         dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= BATCH * 2:
+        if dt >= budget_s:
             break
     return {"value": round(n / dt, 2), "unit": "embeddings/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d images (batches of %d of the bs=256 workload), fp32 torch-CPU oracle, %.1f s" % (n, bs, dt)}

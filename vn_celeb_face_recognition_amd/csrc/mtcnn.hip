@@ -550,6 +550,84 @@ __global__ void __launch_bounds__(256) crop_resize_kernel(const uint8_t* __restr
   }
 }
 
+// Fast path of K5 (rows of W*3 % 16 == 0, crops up to CROP_MAXB bytes wide): each wave owns output
+// rows wave, wave+4, ...; its lanes stream the 16-byte chunks that cover the crop's byte span of
+// every input row of the bin row (coalesced dwordx4 loads instead of per-pixel byte loads), keep
+// per-byte column sums in registers, park them in a wave-private LDS strip, and then add the
+// horizontal bin spans.  Integer sums: bit-identical to the scalar kernel and to the oracle.
+constexpr int CROP_MAXB = 4096;  // bytes of crop row per strip (1365 px)
+
+__global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __restrict__ frames, int H, int W,
+                                                                const Row* __restrict__ rows, const int* __restrict__ row_cnt,
+                                                                int S, float* __restrict__ out, int* __restrict__ status) {
+  __shared__ unsigned strips[4][CROP_MAXB + 32];
+  const int k = blockIdx.x, img = blockIdx.y;
+  if (k >= row_cnt[img]) return;
+  const Row r = rows[(size_t)img * KEEP + k];
+  const int y0 = r.y - 1, x0 = r.x - 1, ch = r.ey - y0, cw = r.ex - x0;
+  float* o = out + ((size_t)img * KEEP + k) * 3 * S * S;
+  if (ch <= 0 || cw <= 0) {
+    for (int i = threadIdx.x; i < 3 * S * S; i += blockDim.x) o[i] = 0.f;
+    if (threadIdx.x == 0) atomicOr(status, ST_DEGENERATE);
+    return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rowb = W * 3, bs = x0 * 3, be = (x0 + cw) * 3;
+  const int c_lo = bs >> 4, nch = ((be + 15) >> 4) - c_lo, off = bs - (c_lo << 4);
+  if (nch * 16 > CROP_MAXB + 32) {  // wider than a strip: per-pixel path for this candidate
+    const uint8_t* base = frames + ((size_t)img * H + y0) * (size_t)W * 3 + (size_t)x0 * 3;
+    for (int i = threadIdx.x; i < S * S; i += blockDim.x) {
+      const int oy = i / S, ox = i - oy * S;
+      const int h0 = (oy * ch) / S, h1 = ((oy + 1) * ch + S - 1) / S;
+      const int w0 = (ox * cw) / S, w1 = ((ox + 1) * cw + S - 1) / S;
+      unsigned s0 = 0, s1 = 0, s2 = 0;
+      for (int yy = h0; yy < h1; ++yy) {
+        const uint8_t* row = base + ((size_t)yy * W + w0) * 3;
+        for (int xx = 0; xx < w1 - w0; ++xx) { s0 += row[3 * xx]; s1 += row[3 * xx + 1]; s2 += row[3 * xx + 2]; }
+      }
+      const float kh = (float)(h1 - h0), kw = (float)(w1 - w0);
+      o[i] = (((float)s0 / kh) / kw - 127.5f) * 0.0078125f;
+      o[S * S + i] = (((float)s1 / kh) / kw - 127.5f) * 0.0078125f;
+      o[2 * S * S + i] = (((float)s2 / kh) / kw - 127.5f) * 0.0078125f;
+    }
+    return;
+  }
+  const uint8_t* fbase = frames + (size_t)img * H * rowb;
+  unsigned* cs = strips[wave];
+  for (int oy = wave; oy < S; oy += 4) {
+    const int h0 = (oy * ch) / S, h1 = ((oy + 1) * ch + S - 1) / S;
+    for (int cbase = 0; cbase < nch; cbase += 64) {
+      const int c = cbase + lane;
+      unsigned acc[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = 0u;
+      if (c < nch) {
+        for (int yy = h0; yy < h1; ++yy) {
+          const uint4 v = *reinterpret_cast<const uint4*>(fbase + (size_t)(y0 + yy) * rowb + ((size_t)(c_lo + c) << 4));
+          const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[d * 4 + e] += (wv[d] >> (8 * e)) & 0xFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cs[c * 16 + j] = acc[j];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float kh = (float)(h1 - h0);
+    for (int q = lane; q < 3 * S; q += 64) {
+      const int cch = q / S, ox = q - cch * S;
+      const int w0 = (ox * cw) / S, w1 = ((ox + 1) * cw + S - 1) / S;
+      unsigned sum = 0;
+      for (int xx = w0; xx < w1; ++xx) sum += cs[off + xx * 3 + cch];
+      o[cch * S * S + oy * S + ox] = (((float)sum / kh) / (float)(w1 - w0) - 127.5f) * 0.0078125f;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // --------------------------------------------------------------------------------------------- K6 building blocks
 // Direct convolution / pooling / dense layers over activations resident in LDS (CHW fp32),
 // weights in their PyTorch layout read through L1/L2 (shared by every workgroup).
@@ -597,6 +675,87 @@ __device__ void lds_conv_prelu(const float* __restrict__ in, int Hi, int Wi, flo
       for (int px = 0; px < PXB; ++px)
         if (x0 + px < Wo) out[(cb * COB + co) * Ho * Wo + y * Wo + x0 + px] = prelu(acc[co][px], a[cb * COB + co]);
   }
+}
+
+// The same register-tiled convolution with the weights of ONE input channel at a time staged in
+// LDS (double-buffered, one barrier per input channel): the inner loop then touches no global
+// memory, which matters at one workgroup per CU where nothing else hides an L2 round trip.
+// Every thread owns NTILE output tiles for the whole channel loop.  wbuf: 2 * KS*KS * cout floats.
+template <int CIN, int KS, int COB, int PXB, int NTILE>
+__device__ void lds_conv_prelu_ws(const float* __restrict__ in, int Hi, int Wi, float* __restrict__ out, int cout,
+                                  const float* __restrict__ wt, int ldw, const float* __restrict__ b,
+                                  const float* __restrict__ a, float* __restrict__ wbuf) {
+  const int Ho = Hi - KS + 1, Wo = Wi - KS + 1;
+  const int xg = (Wo + PXB - 1) / PXB, per_cb = Ho * xg, n = (cout / COB) * per_cb;
+  const int wn = KS * KS * cout;  // floats of one input channel's weights
+  float acc[NTILE][COB][PXB];
+  int tcb[NTILE], ty[NTILE], tx[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) {
+    const int i = threadIdx.x + t * blockDim.x;
+    const int ii = i < n ? i : 0;
+    tcb[t] = ii / per_cb;
+    const int p = ii - tcb[t] * per_cb;
+    ty[t] = p / xg;
+    tx[t] = (p - ty[t] * xg) * PXB;
+    if (i >= n) tcb[t] = -1;
+#pragma unroll
+    for (int co = 0; co < COB; ++co)
+#pragma unroll
+      for (int px = 0; px < PXB; ++px) acc[t][co][px] = tcb[t] >= 0 ? b[tcb[t] * COB + co] : 0.f;
+  }
+  // stage channel 0
+  for (int i = threadIdx.x; i < wn; i += blockDim.x) wbuf[i] = wt[(size_t)(i / cout) * ldw + (i % cout)];
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < CIN; ++c) {
+    float* wcur = wbuf + (c & 1) * wn;
+    float* wnxt = wbuf + ((c + 1) & 1) * wn;
+    // prefetch the next channel's weights into registers (<= 3 per thread), park them after the math
+    float pre[3];
+    const bool more = c + 1 < CIN;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = threadIdx.x + u * blockDim.x;
+      pre[u] = (more && i < wn) ? wt[(size_t)((c + 1) * KS * KS + i / cout) * ldw + (i % cout)] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      if (tcb[t] >= 0) {
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh) {
+          const float* ir = in + c * Hi * Wi + (ty[t] + kh) * Wi + tx[t];
+          float v[PXB + KS - 1];
+#pragma unroll
+          for (int j = 0; j < PXB + KS - 1; ++j) v[j] = (tx[t] + j < Wi) ? ir[j] : 0.f;
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) {
+            const float* ww = wcur + (kh * KS + kw) * cout + tcb[t] * COB;
+#pragma unroll
+            for (int co = 0; co < COB; ++co)
+#pragma unroll
+              for (int px = 0; px < PXB; ++px) acc[t][co][px] = fmaf(v[px + kw], ww[co], acc[t][co][px]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = threadIdx.x + u * blockDim.x;
+      if (more && i < wn) wnxt[i] = pre[u];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t)
+    if (tcb[t] >= 0) {
+#pragma unroll
+      for (int co = 0; co < COB; ++co)
+#pragma unroll
+        for (int px = 0; px < PXB; ++px)
+          if (tx[t] + px < Wo)
+            out[(tcb[t] * COB + co) * Ho * Wo + ty[t] * Wo + tx[t] + px] = prelu(acc[t][co][px], a[tcb[t] * COB + co]);
+    }
 }
 
 // conv + PReLU + MaxPool(PK, 2, ceil_mode=True) fused (recomputes the conv under overlapping windows):
@@ -692,18 +851,19 @@ __global__ void __launch_bounds__(256) rnet_kernel(const float* __restrict__ cro
   if (k >= row_cnt[img]) return;
   float* A = reinterpret_cast<float*>(smem);            // 28*22*22 = 13552 floats
   float* Bf = A + 13552;                                // 28*11*11 = 3388 floats (>= 3*24*24 = 1728)
+  float* Wb = Bf + 3388;                                // 2 * 9 * 48 = 864 floats: staged weights
   const float* src = crops + ((size_t)img * KEEP + k) * 3 * 24 * 24;
   for (int i = threadIdx.x; i < 1728; i += blockDim.x) Bf[i] = src[i];
   __syncthreads();
-  lds_conv_prelu<3, 3, 4, 2>(Bf, 24, 24, A, 28, w.c1w, 28, w.c1b, w.a1);   // 28 x 22 x 22
+  lds_conv_prelu_ws<3, 3, 4, 4, 4>(Bf, 24, 24, A, 28, w.c1w, 28, w.c1b, w.a1, Wb);   // 28 x 22 x 22
   __syncthreads();
-  lds_maxpool_ceil<3>(A, 28, 22, 22, Bf);                                  // 28 x 11 x 11
+  lds_maxpool_ceil<3>(A, 28, 22, 22, Bf);                                            // 28 x 11 x 11
   __syncthreads();
-  lds_conv_prelu<28, 3, 4, 3>(Bf, 11, 11, A, 48, w.c2w, 48, w.c2b, w.a2);  // 48 x 9 x 9
+  lds_conv_prelu_ws<28, 3, 4, 3, 2>(Bf, 11, 11, A, 48, w.c2w, 48, w.c2b, w.a2, Wb);  // 48 x 9 x 9
   __syncthreads();
-  lds_maxpool_ceil<3>(A, 48, 9, 9, Bf);                                    // 48 x 4 x 4
+  lds_maxpool_ceil<3>(A, 48, 9, 9, Bf);                                              // 48 x 4 x 4
   __syncthreads();
-  lds_conv_prelu<48, 2, 4, 1>(Bf, 4, 4, A, 64, w.c3w, 64, w.c3b, w.a3);    // 64 x 3 x 3
+  lds_conv_prelu_ws<48, 2, 4, 1, 1>(Bf, 4, 4, A, 64, w.c3w, 64, w.c3b, w.a3, Wb);    // 64 x 3 x 3
   __syncthreads();
   lds_dense_permuted_prelu(A, 64, 3, 3, A + 1024, A + 2048, Bf, 128, w.d4w, w.d4b, w.a4);
   __syncthreads();
@@ -731,26 +891,32 @@ __global__ void __launch_bounds__(512) onet_kernel(const float* __restrict__ cro
   const int k = blockIdx.x, img = blockIdx.y;
   if (k >= row_cnt[img]) return;
   float* X = reinterpret_cast<float*>(smem);   // 32*23*23 = 16928 floats
-  float* Y = X + 16928;                        // 32*21*21 = 14112 floats (>= 3*48*48 = 6912)
-  float* Z = Y + 14112;                        // 64*10*10 = 6400 floats
+  float* Wk = X + 16928;                       // 14112 floats: conv1 round (4*46*46 = 8464) / conv2 half (32*21*21)
+  float* Q = Wk + 14112;                       // 6912 floats: input (3*48*48), later the 64x10x10 pooled map
+  float* Wb = Q + 6912;                        // 2 * 9 * 64 = 1152 floats: staged weights
   const float* src = crops + ((size_t)img * KEEP + k) * 3 * 48 * 48;
-  for (int i = threadIdx.x; i < 6912; i += blockDim.x) Y[i] = src[i];
+  for (int i = threadIdx.x; i < 6912; i += blockDim.x) Q[i] = src[i];
   __syncthreads();
-  lds_conv_prelu_pool<3, 3, 3>(Y, 48, 48, X, 32, w.c1w, w.c1b, w.a1);     // conv 46x46 -> pool 23x23
-  __syncthreads();
-  for (int half = 0; half < 2; ++half) {  // conv2 in two 32-channel halves: the full 64x21x21 map would not fit LDS
-    lds_conv_prelu<32, 3, 8, 4>(X, 23, 23, Y, 32, w.c2w + half * 32, 64, w.c2b + half * 32, w.a2 + half * 32);
+  for (int rd = 0; rd < 8; ++rd) {  // conv1 3->32 in rounds of 4 channels: the full 32x46x46 map would not fit LDS
+    lds_conv_prelu_ws<3, 3, 4, 4, 2>(Q, 48, 48, Wk, 4, w.c1w + rd * 4, 32, w.c1b + rd * 4, w.a1 + rd * 4, Wb);
     __syncthreads();
-    lds_maxpool_ceil<3>(Y, 32, 21, 21, Z + half * 32 * 100);              // -> 64 x 10 x 10
+    lds_maxpool_ceil<3>(Wk, 4, 46, 46, X + rd * 4 * 529);                 // -> 32 x 23 x 23
     __syncthreads();
   }
-  lds_conv_prelu<64, 3, 4, 2>(Z, 10, 10, Y, 64, w.c3w, 64, w.c3b, w.a3);  // 64 x 8 x 8
+  for (int half = 0; half < 2; ++half) {  // conv2 32->64 in two 32-channel halves
+    lds_conv_prelu_ws<32, 3, 8, 4, 1>(X, 23, 23, Wk, 32, w.c2w + half * 32, 64, w.c2b + half * 32, w.a2 + half * 32, Wb);
+    __syncthreads();
+    lds_maxpool_ceil<3>(Wk, 32, 21, 21, Q + half * 32 * 100);             // -> 64 x 10 x 10
+    __syncthreads();
+  }
+  lds_conv_prelu_ws<64, 3, 4, 2, 1>(Q, 10, 10, Wk, 64, w.c3w, 64, w.c3b, w.a3, Wb);    // 64 x 8 x 8
   __syncthreads();
-  lds_maxpool_ceil<2>(Y, 64, 8, 8, X);                                     // 64 x 4 x 4
+  lds_maxpool_ceil<2>(Wk, 64, 8, 8, X);                                   // 64 x 4 x 4
   __syncthreads();
-  lds_conv_prelu<64, 2, 4, 1>(X, 4, 4, Y, 128, w.c4w, 128, w.c4b, w.a4);  // 128 x 3 x 3
+  lds_conv_prelu_ws<64, 2, 4, 1, 1>(X, 4, 4, Wk, 128, w.c4w, 128, w.c4b, w.a4, Wb);    // 128 x 3 x 3
   __syncthreads();
-  lds_dense_permuted_prelu(Y, 128, 3, 3, Z, Z + 1152, X, 256, w.d5w, w.d5b, w.a5);
+  float* Y = Wk;
+  lds_dense_permuted_prelu(Wk, 128, 3, 3, Q, Q + 1152, X, 256, w.d5w, w.d5b, w.a5);
   __syncthreads();
   if (threadIdx.x < 16) {
     const int o = threadIdx.x;
@@ -1004,7 +1170,7 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
       GETW(d61, wo, "dense6_1.weight", 512) GETW(d61b, wo, "dense6_1.bias", 2)
       GETW(d62, wo, "dense6_2.weight", 1024) GETW(d62b, wo, "dense6_2.bias", 4)
       GETW(d63, wo, "dense6_3.weight", 2560) GETW(d63b, wo, "dense6_3.bias", 10)
-      m->ow = ONetW{UP(c1, 864), UP(b1, 32), UP(a1, 32), up_transposed(*m, c2, 64, 32, 3), UP(b2, 64), UP(a2, 64),
+      m->ow = ONetW{up_transposed(*m, c1, 32, 3, 3), UP(b1, 32), UP(a1, 32), up_transposed(*m, c2, 64, 32, 3), UP(b2, 64), UP(a2, 64),
                     up_transposed(*m, c3, 64, 64, 3), UP(b3, 64), UP(a3, 64), up_transposed(*m, c4, 128, 64, 2), UP(b4, 128),
                     UP(a4, 128), up_transposed(*m, d5, 256, 1152, 1), UP(d5b, 256), UP(a5, 256),
                     UP(d61, 512), UP(d61b, 2), UP(d62, 1024), UP(d62b, 4), UP(d63, 2560), UP(d63b, 10)};
@@ -1043,7 +1209,7 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
       int lds_max = 0;
       VNF_HIP(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, m->device));
       const int need_img = CAP_IMG * 8 + KEEP * 20 + 256 * 20, need_scale = CAP_SCALE * 8 + KEEP * 20 + 256 * 20;
-      const int need_post = KEEP * 44 + 256 * 20, need_r = (13552 + 3388) * 4, need_o = (16928 + 14112 + 6400) * 4;
+      const int need_post = KEEP * 44 + 256 * 20, need_r = (13552 + 3388 + 864) * 4, need_o = (16928 + 14112 + 6912 + 1152) * 4;
       (void)hipFuncSetAttribute((const void*)nms_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_img);
       (void)hipFuncSetAttribute((const void*)nms_scale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_scale);
       (void)hipFuncSetAttribute((const void*)stage2_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_post);
@@ -1117,8 +1283,12 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   for (int i = 0; i < B; ++i) max2 = std::max(max2, h[i]);
   if (max2 == 0) return VNF_OK;
   // ---- stage 2
-  hipLaunchKernelGGL(crop_resize_kernel, dim3(max2, B), dim3(256), 0, s, frames, H, W, m->rows, m->row_cnt, 24, m->crops, m->status);
-  hipLaunchKernelGGL(rnet_kernel, dim3(max2, B), dim3(256), (13552 + 3388) * 4, s, m->crops, m->row_cnt, m->rw, m->rout);
+  const bool crop_fast = (W * 3) % 16 == 0 && ((reinterpret_cast<uintptr_t>(frames)) & 15) == 0;
+  if (crop_fast)
+    hipLaunchKernelGGL(crop_resize_rows_kernel, dim3(max2, B), dim3(256), 0, s, frames, H, W, m->rows, m->row_cnt, 24, m->crops, m->status);
+  else
+    hipLaunchKernelGGL(crop_resize_kernel, dim3(max2, B), dim3(256), 0, s, frames, H, W, m->rows, m->row_cnt, 24, m->crops, m->status);
+  hipLaunchKernelGGL(rnet_kernel, dim3(max2, B), dim3(256), (13552 + 3388 + 864) * 4, s, m->crops, m->row_cnt, m->rw, m->rout);
   const size_t lds_post = (size_t)KEEP * 28 + 256 * 20 + KEEP * 16;
   hipLaunchKernelGGL(stage2_post_kernel, dim3(B), dim3(256), lds_post, s, m->rows, m->row_cnt, m->rout, cfg.thresholds[1], 0.7f,
                      W, H, m->rows3, m->row3_cnt, m->status);
@@ -1129,8 +1299,11 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   for (int i = 0; i < B; ++i) max3 = std::max(max3, h[cfg.max_batch + i]);
   if (max3 == 0) return VNF_OK;
   // ---- stage 3
-  hipLaunchKernelGGL(crop_resize_kernel, dim3(max3, B), dim3(256), 0, s, frames, H, W, m->rows3, m->row3_cnt, 48, m->crops, m->status);
-  hipLaunchKernelGGL(onet_kernel, dim3(max3, B), dim3(512), (16928 + 14112 + 6400) * 4, s, m->crops, m->row3_cnt, m->ow, m->oout);
+  if (crop_fast)
+    hipLaunchKernelGGL(crop_resize_rows_kernel, dim3(max3, B), dim3(256), 0, s, frames, H, W, m->rows3, m->row3_cnt, 48, m->crops, m->status);
+  else
+    hipLaunchKernelGGL(crop_resize_kernel, dim3(max3, B), dim3(256), 0, s, frames, H, W, m->rows3, m->row3_cnt, 48, m->crops, m->status);
+  hipLaunchKernelGGL(onet_kernel, dim3(max3, B), dim3(512), (16928 + 14112 + 6912 + 1152) * 4, s, m->crops, m->row3_cnt, m->ow, m->oout);
   hipLaunchKernelGGL(stage3_post_kernel, dim3(B), dim3(256), lds_post, s, m->rows3, m->row3_cnt, m->oout, cfg.thresholds[2], 0.7f,
                      cfg.select_largest, m->fin, m->fin_cnt, m->status);
   VNF_HIP(hipGetLastError());
