@@ -107,6 +107,58 @@ hipError_t launch_maxpool3s2(const void* x, int ldx, void* y, int ldy, int dtype
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- max pool k x k stride 2, ceil_mode=True
+// (MTCNN R/O-Net pools, mtcnn.py:64,67,114,117,120): windows may hang over the border.
+template <typename T>
+__global__ void maxpool_ceil_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int n, int H, int W,
+                                    int C, int k) {
+  constexpr int CH = 16 / (int)sizeof(T);
+  const int Ho = (H - k + 1) / 2 + 1, Wo = (W - k + 1) / 2 + 1, cc = C / CH;
+  const size_t total = (size_t)n * Ho * Wo * cc;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cc) * CH;
+    const size_t p = i / cc;
+    const int wo = (int)(p % Wo);
+    const size_t q = p / Wo;
+    const int ho = (int)(q % Ho);
+    const size_t img = q / Ho;
+    float m[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) m[e] = -INFINITY;
+    for (int dh = 0; dh < k; ++dh)
+      for (int dw = 0; dw < k; ++dw) {
+        const int yy = 2 * ho + dh, xx = 2 * wo + dw;
+        if (yy < H && xx < W) {
+          T v[CH];
+          *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(x + ((img * H + yy) * W + xx) * (size_t)ldx + c);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+        }
+      }
+    T o[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) o[e] = (T)m[e];
+    *reinterpret_cast<uint4*>(y + p * (size_t)ldy + c) = *reinterpret_cast<const uint4*>(o);
+  }
+}
+
+hipError_t launch_maxpool_ceil(const void* x, int ldx, void* y, int ldy, int dtype, int n, int H, int W, int C, int k,
+                               hipStream_t s) {
+  const int Ho = (H - k + 1) / 2 + 1, Wo = (W - k + 1) / 2 + 1;
+  const int ch = 16 / dtype_size(dtype);
+  if (C % ch) return hipErrorInvalidValue;
+  const size_t total = (size_t)n * Ho * Wo * (C / ch);
+  if (total == 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  switch (dtype) {
+    case BF16: hipLaunchKernelGGL(maxpool_ceil_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)x, ldx, (__bf16*)y, ldy, n, H, W, C, k); break;
+    case F16: hipLaunchKernelGGL(maxpool_ceil_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)x, ldx, (_Float16*)y, ldy, n, H, W, C, k); break;
+    case F32: hipLaunchKernelGGL(maxpool_ceil_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, n, H, W, C, k); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- global average pool
 template <typename T>
 __global__ void avgpool_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int n, int HW, int C) {

@@ -638,6 +638,111 @@ int build_ir100(Encoder& e, WeightMap& wm) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// MTCNN R-Net (mtcnn.py:52-99) and O-Net (102-157) as plans on the exact-f32 MFMA convolution core.
+// Candidates are the batch dimension; the crop kernel writes NHWC4 fp32 crops into buffer 0.
+// dense4 / dense5 consume x.permute(0,3,2,1) flattened (feature (w*H + h)*C + c), i.e. they are a
+// 3x3 "convolution" over the 3x3xC map with weight[o][c][kh=h][kw=w] = dense[o][(w*3 + h)*C + c].
+static int mtcnn_conv(Encoder& e, WeightMap& wm, const std::string& name, const std::string& prelu, int xb, int cin,
+                      int cin_pad, int cout, int cout_pad, int k, int ob) {
+  ConvSpec s;
+  s.name = name; s.x_buf = xb; s.cin = cin; s.cin_pad = cin_pad; s.KH = s.KW = k;
+  s.pieces.resize(1);
+  Piece& pc = s.pieces[0];
+  pc.w = wm.get(name + ".weight", (int64_t)cout * cin * k * k);
+  const float* b = wm.get(name + ".bias", cout);
+  const float* a = wm.get(prelu + ".weight", cout);
+  if (!pc.w || !b || !a) return fail(VNF_E_MISSING, "mtcnn: missing weight " + wm.missing);
+  pc.cout = cout; pc.cout_pad = cout_pad;
+  pc.bias.assign(b, b + cout);
+  pc.slope.assign(a, a + cout);
+  s.segs.push_back({0, cout_pad, ob, 0});
+  s.act = ACT_PRELU;
+  return add_conv(e, s);
+}
+
+static int mtcnn_dense(Encoder& e, WeightMap& wm, const std::string& name, const std::string& prelu, int xb, int C,
+                       int nout, int ob, std::vector<float>& keep) {
+  const float* d = wm.get(name + ".weight", (int64_t)nout * C * 9);
+  const float* b = wm.get(name + ".bias", nout);
+  const float* a = wm.get(prelu + ".weight", nout);
+  if (!d || !b || !a) return fail(VNF_E_MISSING, "mtcnn: missing weight " + wm.missing);
+  keep.assign((size_t)nout * C * 9, 0.f);
+  for (int o = 0; o < nout; ++o)
+    for (int c = 0; c < C; ++c)
+      for (int h = 0; h < 3; ++h)
+        for (int w = 0; w < 3; ++w) keep[(((size_t)o * C + c) * 3 + h) * 3 + w] = d[(size_t)o * C * 9 + (w * 3 + h) * C + c];
+  ConvSpec s;
+  s.name = name; s.x_buf = xb; s.cin = s.cin_pad = C; s.KH = s.KW = 3;
+  s.pieces.resize(1);
+  Piece& pc = s.pieces[0];
+  pc.w = keep.data(); pc.cout = pc.cout_pad = nout;
+  pc.bias.assign(b, b + nout);
+  pc.slope.assign(a, a + nout);
+  s.segs.push_back({0, nout, ob, 0});
+  s.act = ACT_PRELU;
+  return add_conv(e, s);
+}
+
+static int mtcnn_heads(Encoder& e, WeightMap& wm, const std::vector<std::pair<std::string, int>>& heads, int xb, int nin,
+                       int ob, int total_pad) {
+  ConvSpec s;
+  s.name = "heads"; s.x_buf = xb; s.cin = s.cin_pad = nin;
+  s.pieces.resize(heads.size());
+  int tot = 0;
+  for (size_t i = 0; i < heads.size(); ++i) {
+    Piece& pc = s.pieces[i];
+    pc.w = wm.get(heads[i].first + ".weight", (int64_t)heads[i].second * nin);
+    const float* b = wm.get(heads[i].first + ".bias", heads[i].second);
+    if (!pc.w || !b) return fail(VNF_E_MISSING, "mtcnn: missing weight " + wm.missing);
+    pc.cout = heads[i].second;
+    pc.cout_pad = (i + 1 == heads.size()) ? total_pad - tot : heads[i].second;
+    pc.bias.assign(b, b + heads[i].second);
+    tot += pc.cout_pad;
+  }
+  s.segs.push_back({0, total_pad, ob, 0});
+  s.act = ACT_NONE;
+  return add_conv(e, s);
+}
+
+static void add_pool_ceil(Encoder& e, int ib, int ob, int k) {
+  Op op; op.kind = Op::MAXPOOLC; op.a = ib; op.b = ob; op.c = k;
+  e.ops.push_back(op);
+}
+
+int build_rnet(Encoder& e, WeightMap& wm) {
+  e.in_size = 24;
+  const int in = e.add_buf(24, 24, 4), c1 = e.add_buf(22, 22, 32), p1 = e.add_buf(11, 11, 32);
+  const int c2 = e.add_buf(9, 9, 48), p2 = e.add_buf(4, 4, 48), c3 = e.add_buf(3, 3, 64), d4 = e.add_buf(1, 1, 128);
+  const int hd = e.add_buf(1, 1, 8);
+  static thread_local std::vector<float> keep;
+  TRY(mtcnn_conv(e, wm, "conv1", "prelu1", in, 3, 4, 28, 32, 3, c1));
+  add_pool_ceil(e, c1, p1, 3);
+  TRY(mtcnn_conv(e, wm, "conv2", "prelu2", p1, 28, 32, 48, 48, 3, c2));
+  add_pool_ceil(e, c2, p2, 3);
+  TRY(mtcnn_conv(e, wm, "conv3", "prelu3", p2, 48, 48, 64, 64, 2, c3));
+  TRY(mtcnn_dense(e, wm, "dense4", "prelu4", c3, 64, 128, d4, keep));
+  TRY(mtcnn_heads(e, wm, {{"dense5_1", 2}, {"dense5_2", 4}}, d4, 128, hd, 8));
+  return VNF_OK;
+}
+
+int build_onet(Encoder& e, WeightMap& wm) {
+  e.in_size = 48;
+  const int in = e.add_buf(48, 48, 4), c1 = e.add_buf(46, 46, 32), p1 = e.add_buf(23, 23, 32);
+  const int c2 = e.add_buf(21, 21, 64), p2 = e.add_buf(10, 10, 64), c3 = e.add_buf(8, 8, 64), p3 = e.add_buf(4, 4, 64);
+  const int c4 = e.add_buf(3, 3, 128), d5 = e.add_buf(1, 1, 256), hd = e.add_buf(1, 1, 16);
+  static thread_local std::vector<float> keep;
+  TRY(mtcnn_conv(e, wm, "conv1", "prelu1", in, 3, 4, 32, 32, 3, c1));
+  add_pool_ceil(e, c1, p1, 3);
+  TRY(mtcnn_conv(e, wm, "conv2", "prelu2", p1, 32, 32, 64, 64, 3, c2));
+  add_pool_ceil(e, c2, p2, 3);
+  TRY(mtcnn_conv(e, wm, "conv3", "prelu3", p2, 64, 64, 64, 64, 3, c3));
+  add_pool_ceil(e, c3, p3, 2);
+  TRY(mtcnn_conv(e, wm, "conv4", "prelu4", p3, 64, 64, 128, 128, 2, c4));
+  TRY(mtcnn_dense(e, wm, "dense5", "prelu5", c4, 128, 256, d5, keep));
+  TRY(mtcnn_heads(e, wm, {{"dense6_1", 2}, {"dense6_2", 4}, {"dense6_3", 10}}, d5, 256, hd, 16));
+  return VNF_OK;
+}
+
 // Images are independent, so a batch is cut into `nstreams` contiguous parts that run the whole plan
 // concurrently on side streams (fork / join with events on the caller's stream): the small late
 // layers (a few hundred workgroups, latency-bound) of one part fill the CUs the other leaves idle,
@@ -721,6 +826,14 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
           case Op::L2NORM:
             VNF_HIP(launch_l2norm(emb_raw + (size_t)n0 * 512, out + (size_t)n0 * 512, nn, 512, s));
             break;
+          case Op::MAXPOOLC: {
+            const Buf& ib = bufs[op.a];
+            const Buf& ob = bufs[op.b];
+            VNF_HIP(launch_maxpool_ceil(ib.ptr + (size_t)n0 * ib.elems_per_image() * es, ib.C,
+                                        ob.ptr + (size_t)n0 * ob.elems_per_image() * es, ob.C, dtype, nn, ib.H, ib.W, ib.C,
+                                        op.c, s));
+            break;
+          }
           case Op::COPYOUT:
             VNF_HIP(hipMemcpyAsync(out + (size_t)n0 * 512, emb_raw + (size_t)n0 * 512, (size_t)nn * 512 * 4,
                                    hipMemcpyDeviceToDevice, s));
@@ -754,7 +867,7 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
         snprintf(line, sizeof line, "%-28s conv M/img=%-6d N=%-5d K=%-5d %dx%d s%d cfg%-2d %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n",
                  L.name.c_str(), L.Ho * L.Wo, L.cout, L.K, L.KH, L.KW, L.sh, L.cfg, ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
       } else {
-        static const char* kn[] = {"pack", "conv", "maxpool", "avgpool", "l2norm", "copyout"};
+        static const char* kn[] = {"pack", "conv", "maxpool", "avgpool", "l2norm", "copyout", "maxpool_ceil"};
         snprintf(line, sizeof line, "%-28s %-8s %60s %8.4f ms\n", "", kn[op.kind], "", ms[oi]);
       }
       *report += line;

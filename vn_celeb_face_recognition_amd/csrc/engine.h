@@ -69,7 +69,7 @@ struct ConvLayer {
 };
 
 struct Op {
-  enum Kind { PACK, CONV, MAXPOOL, AVGPOOL, L2NORM, COPYOUT } kind;
+  enum Kind { PACK, CONV, MAXPOOL, AVGPOOL, L2NORM, COPYOUT, MAXPOOLC } kind;
   int a = 0, b = 0, c = 0, d = 0, e = 0;  // meaning per kind (see engine.cpp)
 };
 
@@ -99,5 +99,9 @@ struct Encoder : HandleBase {
 
 int build_irv1(Encoder& e, WeightMap& wm);
 int build_ir100(Encoder& e, WeightMap& wm);
+// MTCNN R-Net / O-Net as exact-f32 MFMA plans over NHWC4 candidate crops (input buffer 0 is written by the
+// crop kernel; the last buffer holds the head outputs: 8 floats [a0,a1,reg0..3,-,-] / 16 floats [a0,a1,reg0..3,lm0..9])
+int build_rnet(Encoder& e, WeightMap& wm);
+int build_onet(Encoder& e, WeightMap& wm);
 
 }  // namespace vnf

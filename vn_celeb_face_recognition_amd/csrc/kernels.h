@@ -54,6 +54,10 @@ hipError_t launch_pack_input(const void* x, int x_dtype, void* out, int dtype, i
 hipError_t launch_maxpool3s2(const void* x, int ldx, void* y, int ldy, int dtype, int n, int H, int W, int C,
                              hipStream_t s);
 
+// k x k stride-2 max pool with ceil_mode=True (MTCNN R/O-Net), NHWC slice -> NHWC slice
+hipError_t launch_maxpool_ceil(const void* x, int ldx, void* y, int ldy, int dtype, int n, int H, int W, int C, int k,
+                               hipStream_t s);
+
 // global average pool NHWC (n,HW,C) -> (n,C)
 hipError_t launch_avgpool(const void* x, int ldx, void* y, int dtype, int n, int HW, int C, hipStream_t s);
 

@@ -518,16 +518,35 @@ __global__ void __launch_bounds__(256) nms_image_kernel(const Cand* __restrict__
 // detect_face.py:109-114 / 138-143: imgs[i, :, y-1:ey, x-1:ex] -> imresample(S,S) -> normalise.
 // One workgroup per candidate; output NCHW fp32 (3,S,S).  Degenerate rectangles (the reference
 // silently drops them from im_data, which would desynchronise its tables) are flagged and zeroed.
+// Output addressing of the crop kernels.  Planar: (3,S,S) per candidate at [img][KEEP] (the LDS-resident
+// nets).  Compact NHWC4: candidate offs[img]+k-c0 of a dense batch, 4 floats per pixel (RGB + 0), the
+// input layout of the MFMA R/O-Net plans; candidates outside [c0, c0+cap) are skipped.
+struct CropDst {
+  float* base;      // nullptr: candidate not in this chunk
+  int cs, ps;       // channel stride, pixel stride (floats)
+};
+__device__ __forceinline__ CropDst crop_dst(float* out, const int* offs, int c0, int cap, int img, int k, int S) {
+  if (!offs) return CropDst{out + ((size_t)img * KEEP + k) * 3 * S * S, S * S, 1};
+  const int ci = offs[img] + k - c0;
+  if (ci < 0 || ci >= cap) return CropDst{nullptr, 0, 0};
+  return CropDst{out + (size_t)ci * S * S * 4, 1, 4};
+}
+
 __global__ void __launch_bounds__(256) crop_resize_kernel(const uint8_t* __restrict__ frames, int H, int W,
                                                            const Row* __restrict__ rows, const int* __restrict__ row_cnt,
-                                                           int S, float* __restrict__ out, int* __restrict__ status) {
+                                                           int S, float* __restrict__ out, int* __restrict__ status,
+                                                           const int* __restrict__ offs, int c0, int cap) {
   const int k = blockIdx.x, img = blockIdx.y;
   if (k >= row_cnt[img]) return;
+  const CropDst d = crop_dst(out, offs, c0, cap, img, k, S);
+  if (!d.base) return;
   const Row r = rows[(size_t)img * KEEP + k];
   const int y0 = r.y - 1, x0 = r.x - 1, ch = r.ey - y0, cw = r.ex - x0;
-  float* o = out + ((size_t)img * KEEP + k) * 3 * S * S;
+  float* o = d.base;
+  if (d.ps == 4)
+    for (int i = threadIdx.x; i < S * S; i += blockDim.x) o[i * 4 + 3] = 0.f;
   if (ch <= 0 || cw <= 0) {
-    for (int i = threadIdx.x; i < 3 * S * S; i += blockDim.x) o[i] = 0.f;
+    for (int i = threadIdx.x; i < S * S; i += blockDim.x) { o[i * d.ps] = 0.f; o[i * d.ps + d.cs] = 0.f; o[i * d.ps + 2 * d.cs] = 0.f; }
     if (threadIdx.x == 0) atomicOr(status, ST_DEGENERATE);
     return;
   }
@@ -544,9 +563,9 @@ __global__ void __launch_bounds__(256) crop_resize_kernel(const uint8_t* __restr
       }
     }
     const float kh = (float)(h1 - h0), kw = (float)(w1 - w0);
-    o[i] = ((s0 / kh) / kw - 127.5f) * 0.0078125f;
-    o[S * S + i] = ((s1 / kh) / kw - 127.5f) * 0.0078125f;
-    o[2 * S * S + i] = ((s2 / kh) / kw - 127.5f) * 0.0078125f;
+    o[i * d.ps] = ((s0 / kh) / kw - 127.5f) * 0.0078125f;
+    o[i * d.ps + d.cs] = ((s1 / kh) / kw - 127.5f) * 0.0078125f;
+    o[i * d.ps + 2 * d.cs] = ((s2 / kh) / kw - 127.5f) * 0.0078125f;
   }
 }
 
@@ -559,15 +578,20 @@ constexpr int CROP_MAXB = 4096;  // bytes of crop row per strip (1365 px)
 
 __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __restrict__ frames, int H, int W,
                                                                 const Row* __restrict__ rows, const int* __restrict__ row_cnt,
-                                                                int S, float* __restrict__ out, int* __restrict__ status) {
+                                                                int S, float* __restrict__ out, int* __restrict__ status,
+                                                                const int* __restrict__ offs, int c0, int cap) {
   __shared__ unsigned strips[4][CROP_MAXB + 32];
   const int k = blockIdx.x, img = blockIdx.y;
   if (k >= row_cnt[img]) return;
+  const CropDst d = crop_dst(out, offs, c0, cap, img, k, S);
+  if (!d.base) return;
   const Row r = rows[(size_t)img * KEEP + k];
   const int y0 = r.y - 1, x0 = r.x - 1, ch = r.ey - y0, cw = r.ex - x0;
-  float* o = out + ((size_t)img * KEEP + k) * 3 * S * S;
+  float* o = d.base;
+  if (d.ps == 4)
+    for (int i = threadIdx.x; i < S * S; i += blockDim.x) o[i * 4 + 3] = 0.f;
   if (ch <= 0 || cw <= 0) {
-    for (int i = threadIdx.x; i < 3 * S * S; i += blockDim.x) o[i] = 0.f;
+    for (int i = threadIdx.x; i < S * S; i += blockDim.x) { o[i * d.ps] = 0.f; o[i * d.ps + d.cs] = 0.f; o[i * d.ps + 2 * d.cs] = 0.f; }
     if (threadIdx.x == 0) atomicOr(status, ST_DEGENERATE);
     return;
   }
@@ -586,9 +610,9 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
         for (int xx = 0; xx < w1 - w0; ++xx) { s0 += row[3 * xx]; s1 += row[3 * xx + 1]; s2 += row[3 * xx + 2]; }
       }
       const float kh = (float)(h1 - h0), kw = (float)(w1 - w0);
-      o[i] = (((float)s0 / kh) / kw - 127.5f) * 0.0078125f;
-      o[S * S + i] = (((float)s1 / kh) / kw - 127.5f) * 0.0078125f;
-      o[2 * S * S + i] = (((float)s2 / kh) / kw - 127.5f) * 0.0078125f;
+      o[i * d.ps] = (((float)s0 / kh) / kw - 127.5f) * 0.0078125f;
+      o[i * d.ps + d.cs] = (((float)s1 / kh) / kw - 127.5f) * 0.0078125f;
+      o[i * d.ps + 2 * d.cs] = (((float)s2 / kh) / kw - 127.5f) * 0.0078125f;
     }
     return;
   }
@@ -622,7 +646,7 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
       const int w0 = (ox * cw) / S, w1 = ((ox + 1) * cw + S - 1) / S;
       unsigned sum = 0;
       for (int xx = w0; xx < w1; ++xx) sum += cs[off + xx * 3 + cch];
-      o[cch * S * S + oy * S + ox] = (((float)sum / kh) / (float)(w1 - w0) - 127.5f) * 0.0078125f;
+      o[(oy * S + ox) * d.ps + cch * d.cs] = (((float)sum / kh) / (float)(w1 - w0) - 127.5f) * 0.0078125f;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -842,6 +866,31 @@ struct ONetW {
   const float *c1w, *c1b, *a1, *c2w, *c2b, *a2, *c3w, *c3b, *a3, *c4w, *c4b, *a4, *d5w, *d5b, *a5, *d61w, *d61b, *d62w,
       *d62b, *d63w, *d63b;
 };
+
+// exclusive prefix of the per-frame candidate counts: compact batch index of (img, k) = offs[img] + k
+__global__ void prefix_offsets_kernel(const int* __restrict__ cnt, int B, int* __restrict__ offs) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int acc = 0;
+    for (int i = 0; i < B; ++i) { offs[i] = acc; acc += cnt[i]; }
+    offs[B] = acc;
+  }
+}
+
+// head outputs of the MFMA plans (hw floats per candidate: a0, a1, then the regression / landmark
+// values) -> the per-frame tables the post kernels read: [softmax prob of class 1, values...]
+__global__ void heads_scatter_kernel(const float* __restrict__ heads, int hw, const int* __restrict__ offs,
+                                     const int* __restrict__ cnt, int c0, int cap, float* __restrict__ dst, int nf) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, img = blockIdx.y;
+  if (k >= cnt[img]) return;
+  const int ci = offs[img] + k - c0;
+  if (ci < 0 || ci >= cap) return;
+  const float* hsrc = heads + (size_t)ci * hw;
+  float* o = dst + ((size_t)img * KEEP + k) * nf;
+  const float m = fmaxf(hsrc[0], hsrc[1]);
+  const float e0 = expf(hsrc[0] - m), e1 = expf(hsrc[1] - m);
+  o[0] = e1 / (e0 + e1);
+  for (int i = 1; i < nf; ++i) o[i] = hsrc[1 + i];
+}
 
 // mtcnn.py:84-99.  out: [score, reg0..3] per candidate.
 __global__ void __launch_bounds__(256) rnet_kernel(const float* __restrict__ crops, const int* __restrict__ row_cnt,
@@ -1076,6 +1125,10 @@ struct Mtcnn : HandleBase {
   Row *rows = nullptr, *rows3 = nullptr;
   float *crops = nullptr, *rout = nullptr, *oout = nullptr, *fin = nullptr;
   float *prob_dbg = nullptr, *reg_dbg = nullptr;
+  Encoder *renc = nullptr, *oenc = nullptr;  // R-Net / O-Net plans on the exact-f32 MFMA core (candidates = batch)
+  int r_cap = 0, o_cap = 0;
+  int* offs = nullptr;                        // device: (max_batch + 1) compact-batch offsets
+  ~Mtcnn() override { delete renc; delete oenc; }
   size_t cap_px = 0, cap_p1 = 0, cap_c2 = 0, cap_out = 0;
   std::vector<float> h_fin;
   std::vector<int> h_cnt;
@@ -1175,6 +1228,22 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
                     UP(a4, 128), up_transposed(*m, d5, 256, 1152, 1), UP(d5b, 256), UP(a5, 256),
                     UP(d61, 512), UP(d61b, 2), UP(d62, 1024), UP(d62b, 4), UP(d63, 2560), UP(d63b, 10)};
     }
+    {
+      static const int lds_nets = getenv("VNF_MTCNN_LDSNETS") ? atoi(getenv("VNF_MTCNN_LDSNETS")) : 0;
+      if (!lds_nets) {
+        m->r_cap = std::min(cfg->max_batch * KEEP, 8192);
+        m->o_cap = std::min(cfg->max_batch * KEEP, 2048);
+        m->renc = new Encoder();
+        m->renc->kind = 1; m->renc->arch = -2; m->renc->dtype = F32; m->renc->max_batch = m->r_cap;
+        int rr = build_rnet(*m->renc, wr);
+        if (rr == VNF_OK) rr = m->renc->finalize();
+        m->oenc = new Encoder();
+        m->oenc->kind = 1; m->oenc->arch = -3; m->oenc->dtype = F32; m->oenc->max_batch = m->o_cap;
+        if (rr == VNF_OK) rr = build_onet(*m->oenc, wo);
+        if (rr == VNF_OK) rr = m->oenc->finalize();
+        if (rr != VNF_OK) { delete m; return rr; }
+      }
+    }
     const int B = cfg->max_batch;
     m->cap_table = make_levels(cfg->max_height, cfg->max_width, cfg->min_face_size, (double)cfg->factor);
     // other aspect ratios up to the same bounds can need slightly more: 10 % head-room
@@ -1198,6 +1267,7 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
     m->rout = (float*)m->dalloc((size_t)B * KEEP * 5 * 4);
     m->oout = (float*)m->dalloc((size_t)B * KEEP * 15 * 4);
     m->fin = (float*)m->dalloc((size_t)B * KEEP * 15 * 4);
+    m->offs = (int*)m->dalloc((size_t)(B + 1) * 4);
     if (!m->lvl || !m->p1 || !m->c2 || !m->cand || !m->keep1 || !m->cand_cnt || !m->rows || !m->rows3 || !m->crops ||
         !m->rout || !m->oout || !m->fin || !m->pw.w1 || !m->ow.d63b) {
       delete m;
@@ -1284,11 +1354,35 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   if (max2 == 0) return VNF_OK;
   // ---- stage 2
   const bool crop_fast = (W * 3) % 16 == 0 && ((reinterpret_cast<uintptr_t>(frames)) & 15) == 0;
-  if (crop_fast)
-    hipLaunchKernelGGL(crop_resize_rows_kernel, dim3(max2, B), dim3(256), 0, s, frames, H, W, m->rows, m->row_cnt, 24, m->crops, m->status);
-  else
-    hipLaunchKernelGGL(crop_resize_kernel, dim3(max2, B), dim3(256), 0, s, frames, H, W, m->rows, m->row_cnt, 24, m->crops, m->status);
-  hipLaunchKernelGGL(rnet_kernel, dim3(max2, B), dim3(256), (13552 + 3388 + 864) * 4, s, m->crops, m->row_cnt, m->rw, m->rout);
+  auto crop = [&](const Row* rws, const int* cntp, int maxc, int S, float* dst, const int* offs, int c0, int cap) {
+    if (crop_fast)
+      hipLaunchKernelGGL(crop_resize_rows_kernel, dim3(maxc, B), dim3(256), 0, s, frames, H, W, rws, cntp, S, dst, m->status, offs, c0, cap);
+    else
+      hipLaunchKernelGGL(crop_resize_kernel, dim3(maxc, B), dim3(256), 0, s, frames, H, W, rws, cntp, S, dst, m->status, offs, c0, cap);
+  };
+  // nets on the MFMA core: candidates of all frames form one dense batch, processed in chunks of `cap`
+  auto run_net = [&](Encoder* enc, int cap, const Row* rws, const int* cntp, int maxc, int total, int S, int hw, float* dst,
+                     int nf) -> int {
+    hipLaunchKernelGGL(prefix_offsets_kernel, dim3(1), dim3(64), 0, s, cntp, B, m->offs);
+    for (int c0 = 0; c0 < total; c0 += cap) {
+      const int n = std::min(cap, total - c0);
+      crop(rws, cntp, maxc, S, (float*)enc->bufs[0].ptr, m->offs, c0, n);
+      int rc = enc->run(nullptr, n, VNF_F32, nullptr, s);
+      if (rc != VNF_OK) return rc;
+      hipLaunchKernelGGL(heads_scatter_kernel, dim3((maxc + 63) / 64, B), dim3(64), 0, s, (const float*)enc->bufs.back().ptr, hw,
+                         m->offs, cntp, c0, n, dst, nf);
+    }
+    return VNF_OK;
+  };
+  int total2 = 0;
+  for (int i = 0; i < B; ++i) total2 += h[i];
+  if (m->renc) {
+    r = run_net(m->renc, m->r_cap, m->rows, m->row_cnt, max2, total2, 24, 8, m->rout, 5);
+    if (r != VNF_OK) return r;
+  } else {
+    crop(m->rows, m->row_cnt, max2, 24, m->crops, nullptr, 0, 0);
+    hipLaunchKernelGGL(rnet_kernel, dim3(max2, B), dim3(256), (13552 + 3388 + 864) * 4, s, m->crops, m->row_cnt, m->rw, m->rout);
+  }
   const size_t lds_post = (size_t)KEEP * 28 + 256 * 20 + KEEP * 16;
   hipLaunchKernelGGL(stage2_post_kernel, dim3(B), dim3(256), lds_post, s, m->rows, m->row_cnt, m->rout, cfg.thresholds[1], 0.7f,
                      W, H, m->rows3, m->row3_cnt, m->status);
@@ -1299,11 +1393,15 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   for (int i = 0; i < B; ++i) max3 = std::max(max3, h[cfg.max_batch + i]);
   if (max3 == 0) return VNF_OK;
   // ---- stage 3
-  if (crop_fast)
-    hipLaunchKernelGGL(crop_resize_rows_kernel, dim3(max3, B), dim3(256), 0, s, frames, H, W, m->rows3, m->row3_cnt, 48, m->crops, m->status);
-  else
-    hipLaunchKernelGGL(crop_resize_kernel, dim3(max3, B), dim3(256), 0, s, frames, H, W, m->rows3, m->row3_cnt, 48, m->crops, m->status);
-  hipLaunchKernelGGL(onet_kernel, dim3(max3, B), dim3(512), (16928 + 14112 + 6912 + 1152) * 4, s, m->crops, m->row3_cnt, m->ow, m->oout);
+  int total3 = 0;
+  for (int i = 0; i < B; ++i) total3 += h[cfg.max_batch + i];
+  if (m->oenc) {
+    r = run_net(m->oenc, m->o_cap, m->rows3, m->row3_cnt, max3, total3, 48, 16, m->oout, 15);
+    if (r != VNF_OK) return r;
+  } else {
+    crop(m->rows3, m->row3_cnt, max3, 48, m->crops, nullptr, 0, 0);
+    hipLaunchKernelGGL(onet_kernel, dim3(max3, B), dim3(512), (16928 + 14112 + 6912 + 1152) * 4, s, m->crops, m->row3_cnt, m->ow, m->oout);
+  }
   hipLaunchKernelGGL(stage3_post_kernel, dim3(B), dim3(256), lds_post, s, m->rows3, m->row3_cnt, m->oout, cfg.thresholds[2], 0.7f,
                      cfg.select_largest, m->fin, m->fin_cnt, m->status);
   VNF_HIP(hipGetLastError());
