@@ -4,6 +4,7 @@
 #include "engine.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -124,7 +125,8 @@ ConvArgs Encoder::conv_args(const ConvLayer& L, int n0, int nn) const {
 // workgroups and where the operands sit in the cache hierarchy).  ~1 s at create time.
 int Encoder::autotune() {
   static const int enabled = getenv("VNF_AUTOTUNE") ? atoi(getenv("VNF_AUTOTUNE")) : 1;
-  if (!enabled) return VNF_OK;
+  static const int force = getenv("VNF_FORCE_CFG") ? atoi(getenv("VNF_FORCE_CFG")) : -2;
+  if (!enabled && force < -1) return VNF_OK;
   hipEvent_t e0, e1;
   VNF_HIP(hipEventCreate(&e0));
   VNF_HIP(hipEventCreate(&e1));
@@ -136,7 +138,7 @@ int Encoder::autotune() {
       ConvLayer& L = convs[ops[oi].a];
       float best = 1e30f;
       int best_cfg = -1;
-      for (int cfg = -1; cfg < conv_num_cfgs(); ++cfg) {
+      for (int cfg = -1; enabled && cfg < conv_num_cfgs(); ++cfg) {
         ConvArgs a = conv_args(L, 0, nn);
         a.cfg = cfg;
         if (cfg >= 0 && !conv_cfg_ok(a, cfg)) continue;
@@ -153,9 +155,10 @@ int Encoder::autotune() {
           if (t < ms) ms = t;
         }
         if (ms < best) { best = ms; best_cfg = cfg; }
+        static const int logit = getenv("VNF_AUTOTUNE_LOG") ? atoi(getenv("VNF_AUTOTUNE_LOG")) : 0;
+        if (logit) fprintf(stderr, "autotune %s cfg %d: %.4f ms\n", L.name.c_str(), cfg, ms / 4);
       }
       L.cfg = best_cfg;
-      static const int force = getenv("VNF_FORCE_CFG") ? atoi(getenv("VNF_FORCE_CFG")) : -2;
       if (force >= -1) {
         ConvArgs a = conv_args(L, 0, nn);
         if (force == -1 || conv_cfg_ok(a, force)) L.cfg = force;
