@@ -106,21 +106,40 @@ def run_pipeline(args):
     dev = torch.device("cuda", local)
     NF, PER = 16, 8
     frames, truth = make_frames(NF * 2, PER, seed=rank)
-    det = models.MTCNN(keep_all=True, min_face_size=50, device=dev, max_batch=NF, max_height=1080, max_width=1920)
+    # two detector handles: each gets a host thread and a HIP stream, so one batch's detection runs under the
+    # other's host synchronisations (FacePipeline.submit)
+    det = [models.MTCNN(keep_all=True, min_face_size=50, device=dev, max_batch=NF, max_height=1080, max_width=1920)
+           for _ in range(args.detectors)]
     enc = models.InceptionResnetV1(pretrained=None, compute_dtype=args.dtype, max_batch=256).to(dev).eval()
     clf = models.MLPModel(512, 1001).to(dev).eval()
     pipe = FacePipeline(det, enc, clf, {"label": list(range(1001)), "name": ["c%d" % i for i in range(1001)]}, 160, 0.0)
     batches = [torch.from_numpy(frames[i * NF:(i + 1) * NF]).to(dev) for i in range(2)]
 
-    def step(i):
-        counts, boxes, emb = pipe.embed_frames(batches[i & 1])
-        clf.classify(emb, want_logp=False)
+    inflight = []
+
+    def retire(t):
+        # in submission order: the collective sequence is identical on every rank
+        n = t.n_faces
         if world > 1:
-            vdist.all_gather_embeddings(emb)
-        return sum(counts)
+            with torch.cuda.stream(pipe.embed_stream):
+                vdist.all_gather_embeddings(t.emb)
+        return n
+
+    def step(i):
+        # throughput mode: batches are in flight together (detection streams + embedding stream); every batch is
+        # retired inside the timed region and the closing torch.cuda.synchronize() waits for all device work
+        inflight.append(pipe.submit(batches[i & 1], classify=True))
+        return retire(inflight.pop(0)) if len(inflight) > 2 * args.detectors else 0
+
+    def drain():
+        n = 0
+        while inflight:
+            n += retire(inflight.pop(0))
+        return n
 
     for i in range(args.warmup):
         step(i)
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -128,10 +147,12 @@ def run_pipeline(args):
     t0 = time.perf_counter()
     for i in range(args.steps):
         faces += step(i)
+    faces += drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    pipe.close()
     tot = torch.tensor([wall, float(faces)], dtype=torch.float64, device=dev)
     if world > 1:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); wall = float(mx[0])
@@ -160,6 +181,7 @@ def run_pipeline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="embed", choices=["embed", "pipeline"])
+    ap.add_argument("--detectors", type=int, default=1, help="pipeline workload: detector handles (host threads) per GPU")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)

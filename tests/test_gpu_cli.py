@@ -89,6 +89,39 @@ def test_face_pipeline_resident_equals_stepwise_and_oracle(tmp_path):
     assert k == emb.shape[0] == 4
 
 
+def test_face_pipeline_submit_overlaps_without_changing_results(tmp_path):
+    """FacePipeline.submit (detection and embedding on separate HIP streams, batches in flight together) returns
+    exactly what the one-stream embed_frames path returns, for every batch of a back-to-back sequence."""
+    from vn_celeb_face_recognition_amd import models
+    from vn_celeb_face_recognition_amd.pipeline import FacePipeline
+    from vn_celeb_face_recognition_amd.synth import make_frames
+    frames, _ = make_frames(6, 3, seed=3, height=360, width=640)
+    dev = torch.device("cuda:0")
+    det = models.MTCNN(keep_all=True, min_face_size=40, device=dev, max_batch=2, max_height=360, max_width=640)
+    enc = models.InceptionResnetV1(pretrained=None, compute_dtype="bf16", max_batch=32).to(dev).eval()
+    clf = models.MLPModel(512, 1001).to(dev).eval()
+    pipe = FacePipeline(det, enc, clf, {"label": list(range(1001)), "name": ["c%d" % i for i in range(1001)]}, 160, 0.0)
+    batches = [torch.from_numpy(frames[i * 2:(i + 1) * 2]).to(dev) for i in range(3)]
+    want = []
+    for b in batches:
+        counts, boxes, emb = pipe.embed_frames(b)
+        _, amax, prob = clf.classify(emb, want_logp=False)
+        want.append((counts, boxes.copy(), emb.cpu().numpy(), amax.cpu().numpy(), prob.cpu().numpy()))
+    assert sum(sum(w[0]) for w in want) > 0
+    det2 = models.MTCNN(keep_all=True, min_face_size=40, device=dev, max_batch=2, max_height=360, max_width=640)
+    pipe2 = FacePipeline([det, det2], enc, clf, pipe.label2name, 160, 0.0)   # two detection threads + streams
+    for p in (pipe, pipe2):
+        for rep in range(3):
+            tickets = [p.submit(b) for b in batches]          # all three in flight before any result is read
+            for t, w in zip(tickets, want):
+                counts, boxes, emb, amax, prob = t.result()
+                assert counts == w[0] and np.array_equal(boxes, w[1])
+                assert np.array_equal(emb.cpu().numpy(), w[2])
+                assert np.array_equal(amax.cpu().numpy(), w[3]) and np.array_equal(prob.cpu().numpy(), w[4])
+    pipe2.close()
+    torch.cuda.synchronize()
+
+
 def test_demo_image_and_demo_video_cli(tmp_path):
     ck, l2n = _classifier_files(tmp_path)
     a = load_image("mrDam_HaHo_recog.jpg")

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""GPU box: wall time of the pipeline's parts per 16-frame 1080p batch (detect only / align+embed+classify only /
+sequential / overlapped submit)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from vn_celeb_face_recognition_amd import models
+from vn_celeb_face_recognition_amd.pipeline import FacePipeline, align_faces_device
+from vn_celeb_face_recognition_amd.synth import make_frames
+dev = torch.device("cuda:0")
+NF, PER = 16, 8
+frames, _ = make_frames(NF * 2, PER, seed=0)
+det = models.MTCNN(keep_all=True, min_face_size=50, device=dev, max_batch=NF, max_height=1080, max_width=1920)
+enc = models.InceptionResnetV1(pretrained=None, compute_dtype="bf16", max_batch=256).to(dev).eval()
+clf = models.MLPModel(512, 1001).to(dev).eval()
+pipe = FacePipeline(det, enc, clf, {"label": list(range(1001)), "name": ["c%d" % i for i in range(1001)]}, 160, 0.0)
+batches = [torch.from_numpy(frames[i * NF:(i + 1) * NF]).to(dev) for i in range(2)]
+K = 30
+
+def timeit(fn):
+    for i in range(5): fn(i)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(K): fn(i)
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / K * 1e3
+
+res = [det.detect_device(b) for b in batches]
+def f_detect(i): det.detect_device(batches[i & 1])
+def f_embed(i):
+    counts, boxes, probs, points = res[i & 1]
+    fidx = np.repeat(np.arange(len(counts), dtype=np.int32), counts)
+    _, faces = align_faces_device(batches[i & 1], fidx, boxes, points, pipe.template, 160, want_u8=False, norm_dtype=torch.bfloat16)
+    clf.classify(enc(faces), want_logp=False)
+def f_seq(i):
+    c, b, e = pipe.embed_frames(batches[i & 1]); clf.classify(e, want_logp=False)
+def f_sub(i): pipe.submit(batches[i & 1])
+print("faces/batch", [int(sum(r[0])) for r in res])
+print("detect only        %.3f ms" % timeit(f_detect))
+print("align+embed+clf    %.3f ms" % timeit(f_embed))
+print("sequential         %.3f ms" % timeit(f_seq))
+print("submit (overlap)   %.3f ms" % timeit(f_sub))
+# host-side cost of detect: time with GPU idle between calls is the same thing here (host-synced)
+
+# two detector handles on two host threads (ctypes releases the GIL): does detection overlap with itself?
+import threading
+det2 = models.MTCNN(keep_all=True, min_face_size=50, device=dev, max_batch=NF, max_height=1080, max_width=1920)
+det2.detect_device(batches[0])
+def worker(d, n):
+    torch.cuda.set_device(dev)
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        for i in range(n):
+            d.detect_device(batches[i & 1])
+    s.synchronize()
+for nthreads in (1, 2):
+    ths = [threading.Thread(target=worker, args=(d, K)) for d in (det, det2)[:nthreads]]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for t in ths: t.start()
+    for t in ths: t.join()
+    torch.cuda.synchronize()
+    print("detect x%d threads: %.3f ms per batch" % (nthreads, (time.perf_counter() - t0) / (K * nthreads) * 1e3))

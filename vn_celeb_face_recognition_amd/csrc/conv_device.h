@@ -28,6 +28,7 @@ struct KArgs {  // device-side copy of ConvArgs (POD)
   // patch kernel (conv_patch.hip) geometry: taps, channels per tap, LDS pixel pitch in 16-byte
   // slots, padded row width, virtual (vertically padded) image height, patch bytes
   int KH, KW, Cin, pp, Wp, Hv, patch_bytes;
+  long long* dbg;  // in-kernel stamp buffer of the instrumented build (tools), else null
 };
 
 template <typename T>
@@ -291,5 +292,10 @@ constexpr int patch_epi_bytes(int bm, int bn, int wm) {
 int patch_num_cfgs();
 bool patch_cfg_ok(const ConvArgs& a, int pcfg);
 hipError_t launch_patch(const ConvArgs& a, const KArgs& k, int pcfg, hipStream_t s);
+
+// ---- conv_ws.hip (wave-specialised big-tile kernel; configuration ids follow the patch kernel's)
+int ws_num_cfgs();
+bool ws_cfg_ok(const ConvArgs& a, int wcfg);
+hipError_t launch_ws(const ConvArgs& a, const KArgs& k, int wcfg, hipStream_t s);
 
 }  // namespace vnf

@@ -322,11 +322,12 @@ static const TileCfg kCfgs[] = {
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
-int conv_num_cfgs() { return kNumCfgs + patch_num_cfgs(); }
+int conv_num_cfgs() { return kNumCfgs + patch_num_cfgs() + ws_num_cfgs(); }
 
 static bool dma_capable(const ConvArgs& a) { return (a.Kpad / (128 / dtype_size(a.dtype))) * 8 * 16 <= 24 * 1024; }
 
 bool conv_cfg_ok(const ConvArgs& a, int cfg) {
+  if (cfg >= kNumCfgs + patch_num_cfgs()) return dma_capable(a) && ws_cfg_ok(a, cfg - kNumCfgs - patch_num_cfgs());
   if (cfg >= kNumCfgs) return dma_capable(a) && patch_cfg_ok(a, cfg - kNumCfgs);
   if (cfg < 0 || !dma_capable(a)) return false;
   const TileCfg& c = kCfgs[cfg];
@@ -382,6 +383,8 @@ static hipError_t launch_cfg(int cfg, const KArgs& k, hipStream_t s) {
 template <typename T>
 static hipError_t launch_typed(const ConvArgs& a, const KArgs& k, hipStream_t s) {
   static const int env_reg = getenv("VNF_CONV_REG") ? atoi(getenv("VNF_CONV_REG")) : 0;
+  if (a.cfg >= kNumCfgs + patch_num_cfgs() && !env_reg && k.zero && conv_cfg_ok(a, a.cfg))
+    return launch_ws(a, k, a.cfg - kNumCfgs - patch_num_cfgs(), s);
   if (a.cfg >= kNumCfgs && !env_reg && k.zero && conv_cfg_ok(a, a.cfg)) return launch_patch(a, k, a.cfg - kNumCfgs, s);
   if (a.cfg >= 0 && !env_reg && k.zero && conv_cfg_ok(a, a.cfg)) return launch_cfg<T>(a.cfg, k, s);
   // heuristic: BN must divide every segment boundary; keep ~2 workgroups per CU when possible
@@ -420,7 +423,7 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t s) {
   k.M = a.M; k.Cout = a.Cout; k.tiles_n = 0; k.nblk = 0;
   k.ldres = a.ldres; k.act = a.act; k.out_f32 = a.out_f32;
   k.nseg = a.nseg;
-  k.KH = a.KH; k.KW = a.KW; k.Cin = a.Cin; k.pp = k.Wp = k.Hv = k.patch_bytes = 0;
+  k.KH = a.KH; k.KW = a.KW; k.Cin = a.Cin; k.pp = k.Wp = k.Hv = k.patch_bytes = 0; k.dbg = nullptr;
   for (int i = 0; i < 4; ++i) {
     k.seg_c0[i] = i < a.nseg ? a.seg[i].c0 : 1 << 30;
     k.seg_c1[i] = i < a.nseg ? a.seg[i].c1 : 1 << 30;

@@ -1,0 +1,280 @@
+// Wave-specialised implicit-GEMM convolution for gfx950 (MI355X): big tiles at one workgroup per CU.
+//
+// With one 8-wave workgroup per CU the plain ring kernel (conv_igemm.hip) phase-locks: after the
+// per-K-tile barrier every wave first queues its LDS-DMA pieces -- the texture path accepts about
+// 28 B/clk/CU, so a 48-KiB K tile holds the waves ~1700 cycles at issue -- and only then
+// multiplies, so the MFMA pipes idle during the issue phase and the DMA path idles during the
+// MFMA phase.  Here the roles are split (MI355X_MICROARCH.md "ring-gemm"):
+//   * WM x WN consumer waves (one per SIMD) only read fragments and issue MFMAs (software-
+//     pipelined over half K tiles, so LDS latency hides under the previous half's MFMAs);
+//   * LW loader waves only issue LDS-DMA pieces (im2col gather + swizzle in the source address,
+//     exactly the ring kernel's image) and wait for them with counted vmcnt.
+// One raw s_barrier per K tile joins both roles: after it tile kt has landed (the loaders waited
+// for it) and stage (kt-1) % S is free (the consumers drained their reads of it), so the loaders
+// refill it while the consumers multiply tile kt.  Same K order, operand roles and epilogue as the
+// ring kernel, so results are bit-identical to it.
+#include <cstdio>
+#include <cstdlib>
+
+#include "conv_device.h"
+
+namespace vnf {
+
+template <typename T, int BM, int BN, int WM, int WN, int S, int LW, bool DBG = false>
+__global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_ws_kernel(const KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = (int)sizeof(T);
+  constexpr int CH = 16 / ES, BKE = 128 / ES;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
+  constexpr int NC = WM * WN, NT = (NC + LW) * 64;
+  constexpr int PA = BM / 8, PB = BN / 8;          // 1-KiB pieces (8 rows x 128 B) per K tile
+  constexpr int LA = PA / LW, LB = PB / LW;        // pieces per loader wave
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int CST = BN + 4;
+  constexpr int EPASS = (BM * CST * 4 <= S * STAGE) ? 1 : WM;  // conv_epilogue's pass count
+  static_assert(S >= 3 && PA % LW == 0 && PB % LW == 0, "pieces divide over the loader waves");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bid = xcd_remap(blockIdx.x, a.nblk);
+  const int tile_m = bid / a.tiles_n, tile_n = bid - tile_m * a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nkt = a.nkt;
+
+  int4* sK = reinterpret_cast<int4*>(smem + S * STAGE);
+  for (int i = tid; i < nkt * 8; i += NT) sK[i] = a.ktab[i];
+  __syncthreads();  // gather table visible
+
+  if (wave >= NC) {
+    // ------------------------------------------------------------------ loader wave
+    const int lw = wave - NC;
+    const int prow = lane >> 3, lcol = lane & 7;
+    const int lchunk = lcol ^ prow;  // piece rows start at multiples of 8: (row & 7) == prow
+    const int HoWo = a.Ho * a.Wo;
+    int abase[LA], ahi[LA], awi[LA];
+#pragma unroll
+    for (int p = 0; p < LA; ++p) {
+      const int m = m0 + (lw + p * LW) * 8 + prow;
+      if (m < a.M) {
+        const int n = m / HoWo, r = m - n * HoWo;
+        const int ho = r / a.Wo, wo = r - ho * a.Wo;
+        ahi[p] = ho * a.sh - a.ph;
+        awi[p] = wo * a.sw - a.pw;
+        abase[p] = ((n * a.H + ahi[p]) * a.W + awi[p]) * a.ldx;
+      } else {
+        ahi[p] = -(1 << 24);
+        awi[p] = 0;
+        abase[p] = 0;
+      }
+    }
+    const char* wsrc = a.w + ((size_t)(n0 + lw * 8 + prow) * a.Kpad + lchunk * CH) * ES;
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+    auto issue = [&](int kt) {
+      const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((kt % S) * STAGE) + (unsigned)(lw * 1024));
+      const int4 e = sK[kt * 8 + lchunk];
+#pragma unroll
+      for (int p = 0; p < LA; ++p) {
+        const int hi = ahi[p] + e.y, wi = awi[p] + e.z;
+        const bool ok = e.w && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        const char* src = ok ? a.x + (size_t)(abase[p] + e.x) * ES : a.zero;
+        glds16(src, sbase + p * (LW * 1024));
+      }
+#pragma unroll
+      for (int p = 0; p < LB; ++p)
+        glds16(wsrc + ((size_t)(p * LW * 8) * a.Kpad + (size_t)kt * BKE) * ES, sbase + BM * 128 + p * (LW * 1024));
+    };
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t)
+      if (t < nkt) issue(t);
+    for (int kt = 0; kt < nkt; ++kt) {
+      if constexpr (DBG) {
+        const bool st = a.dbg && blockIdx.x == 600 && lane == 0;
+        long long* d = a.dbg + (wave * 64 + kt) * 4;
+        if (st) d[0] = __builtin_readcyclecounter();
+        if (kt + S - 2 < nkt)
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((S - 2) * (LA + LB)) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (st) d[1] = __builtin_readcyclecounter();
+        asm volatile("s_barrier" ::: "memory");
+        if (st) d[2] = __builtin_readcyclecounter();
+        if (kt + S - 1 < nkt) issue(kt + S - 1);
+        if (st) d[3] = __builtin_readcyclecounter();
+        continue;
+      }
+      if (kt + S - 2 < nkt)
+        wait_dma_and_barrier<(S - 2) * (LA + LB)>();
+      else
+        wait_dma_and_barrier<0>();
+      if (kt + S - 1 < nkt) issue(kt + S - 1);
+    }
+    __syncthreads();
+    for (int pass = 0; pass < EPASS; ++pass) {  // the consumers' epilogue barriers
+      __syncthreads();
+      __syncthreads();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer wave
+  const int wm = wave / WN, wn = wave % WN;
+  const int frow = lane & 15, fgrp = lane >> 4;
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  uint4 xf[2][TM], wf[2][TN];
+  auto read_frags = [&](int kt, int ks) {
+    const char* sA = smem + (kt % S) * STAGE;
+    const char* sB = sA + BM * 128;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * WTM + i * 16 + frow;
+      xf[ks][i] = *reinterpret_cast<const uint4*>(sA + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * WTN + j * 16 + frow;
+      wf[ks][j] = *reinterpret_cast<const uint4*>(sB + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+    }
+  };
+  auto mma = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], wf[ks][j], xf[ks][i]);
+  };
+  bool pend = false;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if constexpr (DBG) {
+      const bool st = a.dbg && blockIdx.x == 600 && lane == 0;
+      long long* d = a.dbg + (wave * 64 + kt) * 4;
+      if (st) d[0] = __builtin_readcyclecounter();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (st) d[1] = __builtin_readcyclecounter();
+      asm volatile("s_barrier" ::: "memory");
+      if (st) d[2] = __builtin_readcyclecounter();
+      read_frags(kt, 0);
+      if (pend) mma(1);
+      pend = BKE / 2 < a.K - kt * BKE;
+      if (pend) read_frags(kt, 1);
+      mma(0);
+      if (st) d[3] = __builtin_readcyclecounter();
+      continue;
+    }
+    wait_dma_and_barrier<0>();  // no DMA of its own: drains this wave's fragment reads, then joins
+    read_frags(kt, 0);
+    if (pend) mma(1);
+    pend = BKE / 2 < a.K - kt * BKE;
+    if (pend) read_frags(kt, 1);
+    mma(0);
+  }
+  if (pend) mma(1);
+  __syncthreads();
+  conv_epilogue<T, BM, BN, WM, WN, S * STAGE>(a, acc, smem, m0, n0);
+}
+
+// ===================================================================== host side
+struct WsCfg { int bm, bn, wm, wn, s, lw; };
+static const WsCfg kWs[] = {
+    {256, 128, 2, 2, 3, 4}, {256, 128, 4, 1, 3, 4}, {128, 128, 2, 2, 3, 4}, {128, 128, 2, 2, 4, 4},
+    {256, 64, 4, 1, 3, 4},  {128, 192, 2, 2, 3, 4}, {128, 256, 2, 2, 3, 4}, {128, 64, 2, 2, 4, 4},
+    {256, 128, 2, 2, 3, 2}, {128, 128, 2, 2, 4, 2}, {128, 192, 2, 2, 3, 2}, {192, 128, 2, 2, 3, 4},
+};
+constexpr int kNumWs = (int)(sizeof(kWs) / sizeof(kWs[0]));
+
+int ws_num_cfgs() { return kNumWs; }
+
+bool ws_cfg_ok(const ConvArgs& a, int wcfg) {
+  if (wcfg < 0 || wcfg >= kNumWs) return false;
+  const WsCfg& c = kWs[wcfg];
+  if (a.Cout <= c.bn / 2) return false;
+  if (((a.Cout + c.bn - 1) / c.bn) * c.bn > a.cout_pad) return false;
+  if ((c.bn % 64) && a.Cout % c.bn) return false;
+  const int lds = c.s * (c.bm + c.bn) * 128 + (a.Kpad / (128 / dtype_size(a.dtype))) * 8 * 16;
+  return lds <= 160 * 1024;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int S, int LW>
+static hipError_t launch_one(const KArgs& k, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm_ws_kernel<T, BM, BN, WM, WN, S, LW>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  KArgs kk = k;
+  const int lds = S * (BM + BN) * 128 + k.nkt * 8 * 16;
+  const int tiles_m = (k.M + BM - 1) / BM;
+  kk.tiles_n = (k.Cout + BN - 1) / BN;
+  kk.nblk = tiles_m * kk.tiles_n;
+  hipLaunchKernelGGL((conv_igemm_ws_kernel<T, BM, BN, WM, WN, S, LW>), dim3(kk.nblk), dim3((WM * WN + LW) * 64), lds, s,
+                     kk);
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_ws_typed(int wcfg, const KArgs& k, hipStream_t s) {
+  switch (wcfg) {
+    case 0: return launch_one<T, 256, 128, 2, 2, 3, 4>(k, s);
+    case 1: return launch_one<T, 256, 128, 4, 1, 3, 4>(k, s);
+    case 2: return launch_one<T, 128, 128, 2, 2, 3, 4>(k, s);
+    case 3: return launch_one<T, 128, 128, 2, 2, 4, 4>(k, s);
+    case 4: return launch_one<T, 256, 64, 4, 1, 3, 4>(k, s);
+    case 5: return launch_one<T, 128, 192, 2, 2, 3, 4>(k, s);
+    case 6: return launch_one<T, 128, 256, 2, 2, 3, 4>(k, s);
+    case 7: return launch_one<T, 128, 64, 2, 2, 4, 4>(k, s);
+    case 8: return launch_one<T, 256, 128, 2, 2, 3, 2>(k, s);
+    case 9: return launch_one<T, 128, 128, 2, 2, 4, 2>(k, s);
+    case 10: return launch_one<T, 128, 192, 2, 2, 3, 2>(k, s);
+    case 11: return launch_one<T, 192, 128, 2, 2, 3, 4>(k, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+// Instrumented launch (tools/stamp_ws.py): VNF_WS_STAMP=<file> dumps per-K-tile s_memtime stamps of workgroup 600
+// of every bf16 {128,192,2,2,3,4} launch with more than 600 workgroups.
+static hipError_t launch_stamped(const KArgs& k, hipStream_t s) {
+  static long long* dbuf = nullptr;
+  const int n = 8 * 64 * 4;
+  if (!dbuf && hipMalloc((void**)&dbuf, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+  (void)hipMemsetAsync(dbuf, 0, n * 8, s);
+  KArgs kk = k;
+  kk.dbg = dbuf;
+  const int lds = 3 * (128 + 192) * 128 + k.nkt * 8 * 16;
+  const int tiles_m = (k.M + 127) / 128;
+  kk.tiles_n = (k.Cout + 191) / 192;
+  kk.nblk = tiles_m * kk.tiles_n;
+  (void)hipFuncSetAttribute((const void*)conv_igemm_ws_kernel<__bf16, 128, 192, 2, 2, 3, 4, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((conv_igemm_ws_kernel<__bf16, 128, 192, 2, 2, 3, 4, true>), dim3(kk.nblk), dim3(512), lds, s, kk);
+  hipError_t e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return e;
+  static long long host[8 * 64 * 4];
+  (void)hipMemcpy(host, dbuf, n * 8, hipMemcpyDeviceToHost);
+  if (FILE* f = fopen(getenv("VNF_WS_STAMP"), "a")) {
+    fprintf(f, "launch M=%d N=%d nkt=%d nblk=%d\n", k.M, k.Cout, k.nkt, kk.nblk);
+    for (int w = 0; w < 8; ++w)
+      for (int kt = 0; kt < k.nkt && kt < 64; ++kt)
+        fprintf(f, "%d %d %lld %lld %lld %lld\n", w, kt, host[(w * 64 + kt) * 4], host[(w * 64 + kt) * 4 + 1],
+                host[(w * 64 + kt) * 4 + 2], host[(w * 64 + kt) * 4 + 3]);
+    fclose(f);
+  }
+  return hipSuccess;
+}
+
+hipError_t launch_ws(const ConvArgs& a, const KArgs& k, int wcfg, hipStream_t s) {
+  if (!ws_cfg_ok(a, wcfg) || !k.zero) return hipErrorInvalidValue;
+  if (getenv("VNF_WS_STAMP") && wcfg == 5 && a.dtype == BF16 && (k.M + 127) / 128 * ((k.Cout + 191) / 192) > 600)
+    return launch_stamped(k, s);
+  switch (a.dtype) {
+    case BF16: return launch_ws_typed<__bf16>(wcfg, k, s);
+    case F16: return launch_ws_typed<_Float16>(wcfg, k, s);
+    case F32: return launch_ws_typed<float>(wcfg, k, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace vnf

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 namespace vnf {
 
@@ -127,17 +128,39 @@ int Encoder::autotune() {
   static const int enabled = getenv("VNF_AUTOTUNE") ? atoi(getenv("VNF_AUTOTUNE")) : 1;
   static const int force = getenv("VNF_FORCE_CFG") ? atoi(getenv("VNF_FORCE_CFG")) : -2;
   if (!enabled && force < -1) return VNF_OK;
+  // VNF_TUNE_CACHE=<file>: reuse the choices of an earlier create on this device (lines "key cfg"); lets a
+  // profiled run show steady-state launches only and brings create time down to the weight upload
+  std::map<std::string, int> cache;
+  const char* cache_path = getenv("VNF_TUNE_CACHE");
+  bool cache_dirty = false;
+  if (cache_path && enabled) {
+    if (FILE* f = fopen(cache_path, "r")) {
+      char key[256];
+      int c;
+      while (fscanf(f, "%255s %d", key, &c) == 2) cache[key] = c;
+      fclose(f);
+    }
+  }
   hipEvent_t e0, e1;
   VNF_HIP(hipEventCreate(&e0));
   VNF_HIP(hipEventCreate(&e1));
   for (const Group& g : groups) {
-    const int part = max_batch >= 64 ? (max_batch + 1) / 2 : max_batch;  // run() cuts the batch over 2 streams
+    int part = (max_batch >= 192 && max_streams > 1) ? (max_batch + 1) / 2 : max_batch;  // run() cuts the batch over 2 streams
+    if (tune_batch > 0 && tune_batch < part) part = tune_batch;
     const int nn = g.chunk < part ? g.chunk : part;
     for (int oi = g.first; oi < g.last; ++oi) {
       if (ops[oi].kind != Op::CONV) continue;
       ConvLayer& L = convs[ops[oi].a];
       float best = 1e30f;
       int best_cfg = -1;
+      char key[256];
+      snprintf(key, sizeof key, "%s/d%d/n%d/M%d/K%d/N%d/v%d", L.name.c_str(), dtype, nn, nn * L.Ho * L.Wo, L.Kpad, L.cout,
+               conv_num_cfgs());
+      const auto hit = cache.find(key);
+      if (hit != cache.end()) {
+        ConvArgs a = conv_args(L, 0, nn);
+        if (hit->second == -1 || conv_cfg_ok(a, hit->second)) { L.cfg = hit->second; continue; }
+      }
       for (int cfg = -1; enabled && cfg < conv_num_cfgs(); ++cfg) {
         ConvArgs a = conv_args(L, 0, nn);
         a.cfg = cfg;
@@ -159,6 +182,7 @@ int Encoder::autotune() {
         if (logit) fprintf(stderr, "autotune %s cfg %d: %.4f ms\n", L.name.c_str(), cfg, ms / 4);
       }
       L.cfg = best_cfg;
+      if (cache_path && enabled) { cache[key] = best_cfg; cache_dirty = true; }
       if (force >= -1) {
         ConvArgs a = conv_args(L, 0, nn);
         if (force == -1 || conv_cfg_ok(a, force)) L.cfg = force;
@@ -167,6 +191,12 @@ int Encoder::autotune() {
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  if (cache_dirty) {
+    if (FILE* f = fopen(cache_path, "w")) {
+      for (auto& kv : cache) fprintf(f, "%s %d\n", kv.first.c_str(), kv.second);
+      fclose(f);
+    }
+  }
   return VNF_OK;
 }
 
@@ -755,7 +785,8 @@ int Encoder::run(const void* x, int n, int x_dtype, float* out, hipStream_t s, s
   if (n == 0) return VNF_OK;
   static const int env_streams = getenv("VNF_STREAMS") ? atoi(getenv("VNF_STREAMS")) : 2;
   int ns = env_streams < 1 ? 1 : (env_streams > 4 ? 4 : env_streams);
-  while (ns > 1 && n / ns < 32) --ns;  // keep parts big enough to fill the chip's early layers
+  if (ns > max_streams) ns = max_streams;
+  while (ns > 1 && n / ns < 96) --ns;  // below ~100 images a part no longer fills the chip: fixed per-launch latency dominates
   if (ns == 1 || report) return run_range(x, 0, n, x_dtype, out, s, report);
   if (!side[0]) {
     for (int i = 0; i < 4; ++i) {

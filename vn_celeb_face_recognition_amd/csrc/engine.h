@@ -93,6 +93,8 @@ struct Encoder : HandleBase {
   ConvArgs conv_args(const ConvLayer& L, int n0, int nn) const;
   int run(const void* x, int n, int x_dtype, float* out, hipStream_t s, std::string* report = nullptr);
   int run_range(const void* x, int i0, int i1, int x_dtype, float* out, hipStream_t s, std::string* report);
+  int max_streams = 4;  // cap on run()'s batch split (1: never fork side streams)
+  int tune_batch = 0;   // batch size the autotuner times at (0: the part size run() uses at max_batch)
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t join_ev[4] = {nullptr, nullptr, nullptr, nullptr}, fork_ev = nullptr;
 };

@@ -1234,10 +1234,14 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
         m->r_cap = std::min(cfg->max_batch * KEEP, 8192);
         m->o_cap = std::min(cfg->max_batch * KEEP, 2048);
         m->renc = new Encoder();
+        m->renc->max_streams = 1;  // the detector shares the GPU with the embedding stream: no forks of its own
+        m->renc->tune_batch = std::max(1, m->r_cap / 2);  // typical stage-2 load, not the capacity
         m->renc->kind = 1; m->renc->arch = -2; m->renc->dtype = F32; m->renc->max_batch = m->r_cap;
         int rr = build_rnet(*m->renc, wr);
         if (rr == VNF_OK) rr = m->renc->finalize();
         m->oenc = new Encoder();
+        m->oenc->max_streams = 1;
+        m->oenc->tune_batch = std::max(1, m->o_cap / 4);
         m->oenc->kind = 1; m->oenc->arch = -3; m->oenc->dtype = F32; m->oenc->max_batch = m->o_cap;
         if (rr == VNF_OK) rr = build_onet(*m->oenc, wo);
         if (rr == VNF_OK) rr = m->oenc->finalize();

@@ -15,6 +15,7 @@ aligned faces and embeddings stay in HBM (the reference round-trips through the 
 detection, OpenCV alignment and embedding: SURVEY.md 3.1), only names / boxes come back.
 """
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -133,6 +134,35 @@ def recognize_celeb(bth_alg_face_list, device, emb_model, classify_model, transf
     return bth_names
 
 
+class Ticket:
+    """One submitted frame batch (FacePipeline.submit).  `done` is set once detection has finished on the host and
+    the embedding work is enqueued; the embeddings / classes are produced on the pipeline's embedding stream."""
+    __slots__ = ("counts", "boxes", "probs", "points", "emb", "amax", "prob", "event", "done", "error")
+
+    def __init__(self):
+        self.counts = self.boxes = self.probs = self.points = None
+        self.emb = self.amax = self.prob = self.event = self.error = None
+        self.done = threading.Event()
+
+    def wait_host(self):
+        self.done.wait()
+        if self.error is not None:
+            raise self.error
+        return self
+
+    @property
+    def n_faces(self):
+        return int(sum(self.wait_host().counts))
+
+    def result(self):
+        """Wait for the detection, order the caller's current stream after the embedding work; returns
+        (counts, boxes, emb, amax, prob)."""
+        self.wait_host()
+        if self.event is not None:
+            torch.cuda.current_stream(self.emb.device).wait_event(self.event)
+        return self.counts, self.boxes, self.emb, self.amax, self.prob
+
+
 class FacePipeline:
     """detect -> align -> embed -> classify with every intermediate resident in HBM.
 
@@ -142,13 +172,17 @@ class FacePipeline:
     (optionally) embeddings come back."""
 
     def __init__(self, detector, encoder, classifier, label2name, target_size, threshold=0.0):
-        self.detector, self.encoder, self.classifier = detector, encoder, classifier
+        self.detectors = list(detector) if isinstance(detector, (list, tuple)) else [detector]
+        self.detector, self.encoder, self.classifier = self.detectors[0], encoder, classifier
         self.label2name = label2name
         self.size = int(target_size)
         self.template = center_point_dict[str((self.size, self.size))]
         self.threshold = threshold
         self.in_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16}.get(
             getattr(encoder, "compute_dtype", "f32"), torch.float32)
+        self._det_streams = self._emb_stream = self._threads = self._queues = None
+        self._enc_lock = threading.Lock()
+        self._next = 0
 
     def embed_frames(self, frames_dev):
         """frames_dev (B,H,W,3) u8 cuda -> (counts, boxes (n,4) host, embeddings (n,512) cuda)."""
@@ -160,6 +194,87 @@ class FacePipeline:
         _, faces = align_faces_device(frames_dev, fidx, boxes, points, self.template, self.size, want_u8=False,
                                       norm_dtype=self.in_dtype)
         return counts, boxes, self.encoder(faces)
+
+    def _detect_embed(self, k, frames_dev, ready, t, classify):
+        """detection on detector k's stream, then (under the encoder lock) alignment + embedding + classification
+        on the shared embedding stream"""
+        dev = frames_dev.device
+        det_s = self._det_streams[k]
+        det_s.wait_event(ready)
+        with torch.cuda.stream(det_s):
+            t.counts, t.boxes, t.probs, t.points = self.detectors[k].detect_device(frames_dev)
+        frames_dev.record_stream(det_s)
+        if len(t.boxes):
+            with self._enc_lock:
+                emb_s = self._emb_stream
+                emb_s.wait_event(ready)
+                with torch.cuda.stream(emb_s):
+                    fidx = np.repeat(np.arange(len(t.counts), dtype=np.int32), t.counts)
+                    _, faces = align_faces_device(frames_dev, fidx, t.boxes, t.points, self.template, self.size,
+                                                  want_u8=False, norm_dtype=self.in_dtype)
+                    t.emb = self.encoder(faces)
+                    if classify:
+                        _, t.amax, t.prob = self.classifier.classify(t.emb, want_logp=False)
+                    t.event = emb_s.record_event()
+                frames_dev.record_stream(emb_s)
+        else:
+            t.emb = torch.empty((0, 512), dtype=torch.float32, device=dev)
+
+    def _worker(self, k, dev):
+        torch.cuda.set_device(dev)
+        while True:
+            job = self._queues[k].get()
+            if job is None:
+                return
+            frames_dev, ready, t, classify = job
+            try:
+                self._detect_embed(k, frames_dev, ready, t, classify)
+            except BaseException as e:   # surfaced by ticket.result()
+                t.error = e
+            t.done.set()
+
+    def submit(self, frames_dev, classify=True):
+        """Throughput mode: enqueue one frame batch and return a ticket without waiting for it.
+
+        Detection runs on a detection stream (it synchronises with the host three times to size the candidate
+        tables: detect_face.py's own stage boundaries); alignment + embedding (+ classification) run on the
+        embedding stream, so the embedding of batch i overlaps the detection of batch i+1.  With several
+        detector handles (`FacePipeline(detector=[d0, d1], ...)`) each gets a host thread and a stream, so
+        detections also overlap each other across their host synchronisations; batches go round-robin and
+        `ticket.result()` returns them in submission order regardless of completion order."""
+        dev = frames_dev.device
+        if self._det_streams is None:
+            self._det_streams = [torch.cuda.Stream(device=dev) for _ in self.detectors]
+            self._emb_stream = torch.cuda.Stream(device=dev)
+            if len(self.detectors) > 1:
+                import queue
+                self._queues = [queue.Queue() for _ in self.detectors]
+                self._threads = [threading.Thread(target=self._worker, args=(k, dev), daemon=True)
+                                 for k in range(len(self.detectors))]
+                for th in self._threads:
+                    th.start()
+        ready = torch.cuda.current_stream(dev).record_event()
+        t = Ticket()
+        if len(self.detectors) == 1:
+            self._detect_embed(0, frames_dev, ready, t, classify)
+            t.done.set()
+        else:
+            self._queues[self._next % len(self.detectors)].put((frames_dev, ready, t, classify))
+            self._next += 1
+        return t
+
+    def close(self):
+        """Stop the detection threads (idempotent)."""
+        if self._threads:
+            for q in self._queues:
+                q.put(None)
+            for th in self._threads:
+                th.join()
+            self._threads = None
+
+    @property
+    def embed_stream(self):
+        return self._emb_stream
 
     def recognize_frames(self, rgb_images):
         """list of equal-size HWC u8 RGB frames (or a (B,H,W,3) array / cuda tensor) ->
