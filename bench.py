@@ -112,7 +112,8 @@ def run_pipeline(args):
            for _ in range(args.detectors)]
     enc = models.InceptionResnetV1(pretrained=None, compute_dtype=args.dtype, max_batch=256).to(dev).eval()
     clf = models.MLPModel(512, 1001).to(dev).eval()
-    pipe = FacePipeline(det, enc, clf, {"label": list(range(1001)), "name": ["c%d" % i for i in range(1001)]}, 160, 0.0)
+    pipe = FacePipeline(det, enc, clf, {"label": list(range(1001)), "name": ["c%d" % i for i in range(1001)]}, 160, 0.0,
+                        embed_batch=args.embed_batch)
     batches = [torch.from_numpy(frames[i * NF:(i + 1) * NF]).to(dev) for i in range(2)]
 
     inflight = []
@@ -132,6 +133,7 @@ def run_pipeline(args):
         return retire(inflight.pop(0)) if len(inflight) > 2 * args.detectors else 0
 
     def drain():
+        pipe.flush()
         n = 0
         while inflight:
             n += retire(inflight.pop(0))
@@ -165,7 +167,8 @@ def run_pipeline(args):
                "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[2]+[3]: MTCNN detect + align + IRv1 embed + MLP classify, "
-                                      "synthetic 1080p frames, %d frames/step/GPU, %d pasted faces/frame" % (NF, PER),
+                                      "synthetic 1080p frames, %d frames/step/GPU, %d pasted faces/frame; detection and embedding on "
+                                      "separate streams, faces embedded in groups of >= %d" % (NF, PER, args.embed_batch),
                           "frames_per_s": round(world * NF * args.steps / wall, 1), "min_face_size": 50},
                "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                             "frac": round(achieved / 8000.0, 5), "traffic": None,
@@ -181,6 +184,9 @@ def run_pipeline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="embed", choices=["embed", "pipeline"])
+    ap.add_argument("--embed-batch", type=int, default=256,
+                    help="pipeline workload: faces of consecutive frame batches are embedded together once this many wait "
+                         "(0: every frame batch on its own)")
     ap.add_argument("--detectors", type=int, default=1, help="pipeline workload: detector handles (host threads) per GPU")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)

@@ -94,6 +94,11 @@ int vnf_encoder_profile(vnf_handle h, const void* x, int n, int x_dtype, float* 
  * included) and as the algorithm defines it; used by bench.py for the roofline line. */
 int vnf_encoder_flops(vnf_handle h, double* algorithmic, double* executed);
 
+/* vnf_embed cuts batches of >= 192 images over two internal HIP streams (one half each) to hide the small
+ * layers' launch latencies.  A caller that already runs other work beside the encoder (the pipeline's detection
+ * stream) sets 1: the forks then only take turns with that work.  Default 4 = the library decides. */
+int vnf_encoder_set_streams(vnf_handle h, int max_streams);
+
 /* classifier ------------------------------------------------------------------------------- */
 int vnf_mlp_create(const vnf_tensor_desc* weights, int n_weights, int input_dim, int num_classes,
                    int max_batch, vnf_handle* out);
@@ -125,6 +130,13 @@ int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const vnf_tensor_d
 int vnf_mtcnn_detect(vnf_handle h, const uint8_t* frames, int b, int height, int width,
                      int32_t* counts, float* boxes, float* probs, float* points, int max_out,
                      int32_t* n_out, void* stream);
+
+/* Device-resident copy of the LAST vnf_mtcnn_detect on this handle (same order as its host arrays): writes up to
+ * max_out faces into caller-owned device buffers on `stream` (any of the four may be NULL).  This is what lets
+ * vnf_align consume the detections without the host round trip of demo_image.py:283-295 (boxes and landmarks go
+ * detector -> host -> OpenCV there).  Valid until the next vnf_mtcnn_detect on the handle. */
+int vnf_mtcnn_results_device(vnf_handle h, int32_t* frame_idx, float* boxes, float* probs, float* points,
+                             int max_out, void* stream);
 
 /* staged parity hook: runs the cascade on frame 0 and copies one pyramid level (3,Hs,Ws), its
  * P-Net face-probability map (oh,ow) and regression map (4,oh,ow) to host arrays.

@@ -147,3 +147,35 @@ def test_pyramid_fast_path_bit_exact_and_synthetic_1080p_batch():
         for (x0, y0, x1, y1) in t:                       # every pasted crop contains a detection centre
             cx, cy = (np.asarray(b)[:, 0] + np.asarray(b)[:, 2]) / 2, (np.asarray(b)[:, 1] + np.asarray(b)[:, 3]) / 2
             assert ((cx > x0) & (cx < x1) & (cy > y0) & (cy < y1)).any()
+
+
+def test_result_readback_paths_agree(monkeypatch):
+    """The one-copy pinned read-back (<= 32 faces per frame) and the 2-D copy taken by busier frames return the
+    same detections (VNF_FIN_FAST lowers the limit so ordinary frames take the second path), and both equal the
+    oracle on a 1080p batch: exercises the large-box crop path (row groups split over workgroups) as well."""
+    from vn_celeb_face_recognition_amd.models import MTCNN
+    from vn_celeb_face_recognition_amd.synth import make_frames
+    frames, _ = make_frames(2, 6, seed=5)
+    det = MTCNN(keep_all=True, min_face_size=50, device="cuda:0", max_batch=2)
+    b1, p1, l1 = det.inference(list(frames), landmark=True)
+    monkeypatch.setenv("VNF_FIN_FAST", "1")
+    det_slow = MTCNN(keep_all=True, min_face_size=50, device="cuda:0", max_batch=2)
+    b2, p2, l2 = det_slow.inference(list(frames), landmark=True)
+    assert max(len(b) for b in b1) > 1
+    # the device-resident copy of the detections (vnf_mtcnn_results_device) is the host arrays, frame by frame
+    n = sum(len(b) for b in b1)
+    fidx, bd, pd, ld = (x.cpu().numpy() for x in det.results_device(n))
+    assert np.array_equal(fidx, np.repeat(np.arange(2), [len(b) for b in b1]))
+    assert np.array_equal(bd, np.concatenate([np.asarray(b).reshape(-1, 4) for b in b1]))
+    assert np.array_equal(pd, np.concatenate([np.asarray(p).reshape(-1) for p in p1]))
+    assert np.array_equal(ld, np.concatenate([np.asarray(l).reshape(-1, 10) for l in l1]))
+    for i in range(2):
+        assert np.array_equal(np.asarray(b1[i]), np.asarray(b2[i]))
+        assert np.array_equal(np.asarray(p1[i]), np.asarray(p2[i]))
+        assert np.array_equal(np.asarray(l1[i]), np.asarray(l2[i]))
+    p, r, o = mtcnn_state_dicts()
+    ob, op_, ol = om.mtcnn_detect(list(frames), p, r, o, min_face_size=50, ties="table")
+    for i in range(2):
+        assert len(ob[i]) == len(b1[i])
+        assert np.abs(np.asarray(b1[i]).reshape(-1, 4) - np.asarray(ob[i]).reshape(-1, 4)).max() <= 1e-3
+        assert np.abs(np.asarray(l1[i]).reshape(-1, 10) - np.asarray(ol[i]).reshape(-1, 10)).max() <= 1e-3

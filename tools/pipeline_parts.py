@@ -58,3 +58,17 @@ for nthreads in (1, 2):
     for t in ths: t.join()
     torch.cuda.synchronize()
     print("detect x%d threads: %.3f ms per batch" % (nthreads, (time.perf_counter() - t0) / (K * nthreads) * 1e3))
+
+# host-side enqueue cost of the embedding part (no device wait inside the loop)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(K):
+    f_embed(i)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+print("align+embed+clf host enqueue: %.3f ms per batch (device total %.3f)" % ((t1 - t0) / K * 1e3, (time.perf_counter() - t0) / K * 1e3))
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for i in range(K): f_embed(i)
+pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(12)

@@ -29,8 +29,10 @@ __device__ __forceinline__ int sat_int(double v) {
   return (int)v;
 }
 
+struct Tmpl5 { float v[10]; };  // the 5-point template travels as a kernel argument: no H2D copy on the launch path
+
 __global__ void align_setup_kernel(const int32_t* __restrict__ frame_idx, const float* __restrict__ boxes,
-                                   const float* __restrict__ points, const float* __restrict__ tmpl, int n, int H,
+                                   const float* __restrict__ points, const Tmpl5 tmpl, int n, int H,
                                    int W, FaceXf* __restrict__ xf) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -47,8 +49,8 @@ __global__ void align_setup_kernel(const int32_t* __restrict__ frame_idx, const 
   for (int k = 0; k < 5; ++k) {
     px[k] = (double)(points[10 * i + 2 * k] - b[0]);
     py[k] = (double)(points[10 * i + 2 * k + 1] - b[1]);
-    qx[k] = (double)tmpl[2 * k];
-    qy[k] = (double)tmpl[2 * k + 1];
+    qx[k] = (double)tmpl.v[2 * k];
+    qy[k] = (double)tmpl.v[2 * k + 1];
     pmx += px[k]; pmy += py[k]; qmx += qx[k]; qmy += qy[k];
   }
   pmx /= 5; pmy /= 5; qmx /= 5; qmy /= 5;
@@ -129,12 +131,11 @@ extern "C" int vnf_align(const uint8_t* frames, int b, int height, int width, co
   if (!frames || !boxes || !points || !template5x2 || n < 0 || s <= 0 || b <= 0 || (!faces_u8 && !faces_norm))
     return fail(VNF_E_INVALID, "vnf_align: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  // per-call scratch (n * 72 B + 40 B template) from the stream-ordered allocator: no sync
+  // per-call scratch (n * 72 B) from the stream-ordered allocator: no sync
   FaceXf* xf = nullptr;
-  float* tmpl = nullptr;
-  VNF_HIP(hipMallocAsync((void**)&xf, sizeof(FaceXf) * (size_t)n + 64, st));
-  tmpl = reinterpret_cast<float*>(reinterpret_cast<char*>(xf) + sizeof(FaceXf) * (size_t)n);
-  VNF_HIP(hipMemcpyAsync(tmpl, template5x2, 40, hipMemcpyHostToDevice, st));
+  Tmpl5 tmpl;
+  for (int i = 0; i < 10; ++i) tmpl.v[i] = template5x2[i];
+  VNF_HIP(hipMallocAsync((void**)&xf, sizeof(FaceXf) * (size_t)n, st));
   hipLaunchKernelGGL(align_setup_kernel, dim3((n + 63) / 64), dim3(64), 0, st, frame_idx, boxes, points, tmpl, n, height,
                      width, xf);
   const size_t total = (size_t)n * s * s;

@@ -130,4 +130,14 @@ int vnf_encoder_flops(vnf_handle h, double* algorithmic, double* executed) {
   API_GUARD_END
 }
 
+int vnf_encoder_set_streams(vnf_handle h, int max_streams) {
+  API_GUARD_BEGIN
+  Encoder* e = as_encoder(h);
+  if (!e) return fail(VNF_E_INVALID, "not an encoder handle");
+  if (max_streams < 1 || max_streams > 4) return fail(VNF_E_INVALID, "vnf_encoder_set_streams: 1..4");
+  e->max_streams = max_streams;
+  return VNF_OK;
+  API_GUARD_END
+}
+
 }  // extern "C"

@@ -114,23 +114,24 @@ __global__ void maxpool_ceil_kernel(const T* __restrict__ x, int ldx, T* __restr
                                     int C, int k) {
   constexpr int CH = 16 / (int)sizeof(T);
   const int Ho = (H - k + 1) / 2 + 1, Wo = (W - k + 1) / 2 + 1, cc = C / CH;
-  const size_t total = (size_t)n * Ho * Wo * cc;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cc) * CH;
-    const size_t p = i / cc;
-    const int wo = (int)(p % Wo);
-    const size_t q = p / Wo;
-    const int ho = (int)(q % Ho);
-    const size_t img = q / Ho;
+  const unsigned total = (unsigned)n * Ho * Wo * cc;  // < 2^31, checked by the launcher: 32-bit index math
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned p = i / cc;
+    const int c = (int)(i - p * cc) * CH;
+    const unsigned q = p / Wo;
+    const int wo = (int)(p - q * Wo);
+    const unsigned img = q / Ho;
+    const int ho = (int)(q - img * Ho);
     float m[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) m[e] = -INFINITY;
+    const T* xi = x + (size_t)img * H * W * ldx + c;
     for (int dh = 0; dh < k; ++dh)
       for (int dw = 0; dw < k; ++dw) {
         const int yy = 2 * ho + dh, xx = 2 * wo + dw;
         if (yy < H && xx < W) {
           T v[CH];
-          *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(x + ((img * H + yy) * W + xx) * (size_t)ldx + c);
+          *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(xi + (unsigned)(yy * W + xx) * (size_t)ldx);
 #pragma unroll
           for (int e = 0; e < CH; ++e) m[e] = fmaxf(m[e], (float)v[e]);
         }
@@ -138,7 +139,7 @@ __global__ void maxpool_ceil_kernel(const T* __restrict__ x, int ldx, T* __restr
     T o[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) o[e] = (T)m[e];
-    *reinterpret_cast<uint4*>(y + p * (size_t)ldy + c) = *reinterpret_cast<const uint4*>(o);
+    *reinterpret_cast<uint4*>(y + (size_t)p * ldy + c) = *reinterpret_cast<const uint4*>(o);
   }
 }
 
@@ -149,7 +150,8 @@ hipError_t launch_maxpool_ceil(const void* x, int ldx, void* y, int ldy, int dty
   if (C % ch) return hipErrorInvalidValue;
   const size_t total = (size_t)n * Ho * Wo * (C / ch);
   if (total == 0) return hipSuccess;
-  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (total >= (1u << 31)) return hipErrorInvalidValue;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   switch (dtype) {
     case BF16: hipLaunchKernelGGL(maxpool_ceil_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)x, ldx, (__bf16*)y, ldy, n, H, W, C, k); break;
     case F16: hipLaunchKernelGGL(maxpool_ceil_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)x, ldx, (_Float16*)y, ldy, n, H, W, C, k); break;

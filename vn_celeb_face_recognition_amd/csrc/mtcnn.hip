@@ -32,6 +32,8 @@
 
 namespace vnf {
 
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
 constexpr int MAX_LEVELS = 24;
 constexpr int CAP_SCALE = 4096;  // candidates per (level, frame) before NMS (12-bit slot in the sort key)
 constexpr int CAP_IMG = 8192;    // candidates per frame entering the cross-scale NMS
@@ -177,8 +179,11 @@ __global__ void pnet_conv1_pool_kernel(const float* __restrict__ lvl, LevelTable
     for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 4; ++dx) {
-        const int yy = 2 * py + dy, xx = 2 * px + dx;
-        in[c][dy][dx] = (yy < L.Hs && xx < L.Ws) ? src[(size_t)c * t.tot_px + yy * L.Ws + xx] : 0.f;
+        // clamped address, no predicate: the 48 loads issue back to back instead of one exec-masked round
+        // trip each.  A clamped (out-of-level) value only reaches conv outputs beyond (Hc, Wc), which the
+        // window test below skips, so it never contributes.
+        const int yy = min(2 * py + dy, L.Hs - 1), xx = min(2 * px + dx, L.Ws - 1);
+        in[c][dy][dx] = src[(size_t)c * t.tot_px + yy * L.Ws + xx];
       }
   float best[10];
 #pragma unroll
@@ -188,9 +193,9 @@ __global__ void pnet_conv1_pool_kernel(const float* __restrict__ lvl, LevelTable
 #pragma unroll
     for (int ox = 0; ox < 2; ++ox) {
       if (2 * py + oy < Hc && 2 * px + ox < Wc) {
-        float acc[10];
+        float2_t acc2[5];
 #pragma unroll
-        for (int co = 0; co < 10; ++co) acc[co] = w.b1[co];
+        for (int j = 0; j < 5; ++j) acc2[j] = float2_t{w.b1[2 * j], w.b1[2 * j + 1]};
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -198,13 +203,15 @@ __global__ void pnet_conv1_pool_kernel(const float* __restrict__ lvl, LevelTable
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
               const float v = in[c][oy + kh][ox + kw];
+              const float2_t v2 = {v, v};
               const float* ww = w.w1 + ((c * 3 + kh) * 3 + kw) * 10;
 #pragma unroll
-              for (int co = 0; co < 10; ++co) acc[co] = fmaf(v, ww[co], acc[co]);
+              for (int j = 0; j < 5; ++j) acc2[j] = __builtin_elementwise_fma(v2, float2_t{ww[2 * j], ww[2 * j + 1]}, acc2[j]);
             }
 #pragma unroll
         for (int co = 0; co < 10; ++co) {
-          const float a = acc[co] > 0.f ? acc[co] : acc[co] * w.a1[co];
+          const float av = acc2[co >> 1][co & 1];
+          const float a = av > 0.f ? av : av * w.a1[co];
           best[co] = fmaxf(best[co], a);
         }
       }
@@ -223,9 +230,9 @@ __global__ void pnet_conv2_kernel(const float* __restrict__ p1, LevelTable t, PN
   const LevelDesc L = t.l[li];
   const int p = idx - L.off_c2, y = p / L.W2, x = p - y * L.W2;
   const float* src = p1 + ((size_t)img * 10) * t.tot_p1 + L.off_p1;
-  float acc[16];
+  float2_t acc2[8];
 #pragma unroll
-  for (int co = 0; co < 16; ++co) acc[co] = w.b2[co];
+  for (int j = 0; j < 8; ++j) acc2[j] = float2_t{w.b2[2 * j], w.b2[2 * j + 1]};
 #pragma unroll 1
   for (int c = 0; c < 10; ++c) {
     const float* sc = src + (size_t)c * t.tot_p1 + y * L.Wp + x;
@@ -234,14 +241,18 @@ __global__ void pnet_conv2_kernel(const float* __restrict__ p1, LevelTable t, PN
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const float v = sc[kh * L.Wp + kw];
+        const float2_t v2 = {v, v};
         const float* ww = w.w2 + ((c * 3 + kh) * 3 + kw) * 16;
 #pragma unroll
-        for (int co = 0; co < 16; ++co) acc[co] = fmaf(v, ww[co], acc[co]);
+        for (int j = 0; j < 8; ++j) acc2[j] = __builtin_elementwise_fma(v2, float2_t{ww[2 * j], ww[2 * j + 1]}, acc2[j]);
       }
   }
   float* o = c2 + ((size_t)img * 16) * t.tot_c2 + L.off_c2 + p;
 #pragma unroll
-  for (int co = 0; co < 16; ++co) o[(size_t)co * t.tot_c2] = acc[co] > 0.f ? acc[co] : acc[co] * w.a2[co];
+  for (int co = 0; co < 16; ++co) {
+    const float a = acc2[co >> 1][co & 1];
+    o[(size_t)co * t.tot_c2] = a > 0.f ? a : a * w.a2[co];
+  }
 }
 
 // mtcnn.py:44-49: conv3 16->32 + PReLU, conv4_1 (1x1 ->2) + softmax, conv4_2 (1x1 -> 4);
@@ -257,9 +268,11 @@ __global__ void pnet_conv3_heads_kernel(const float* __restrict__ c2, LevelTable
   const LevelDesc L = t.l[li];
   const int p = idx - L.off_out, y = p / L.ow, x = p - y * L.ow;
   const float* src = c2 + ((size_t)img * 16) * t.tot_c2 + L.off_c2;
-  float acc[32];
+  // two output channels per v_pk_fma_f32: the same IEEE fma per channel in the same (c,kh,kw) order, at twice
+  // the scalar-FMA rate (this kernel is FMA-bound: 4608 FMAs per output cell)
+  float2_t acc2[16];
 #pragma unroll
-  for (int co = 0; co < 32; ++co) acc[co] = w.b3[co];
+  for (int j = 0; j < 16; ++j) acc2[j] = float2_t{w.b3[2 * j], w.b3[2 * j + 1]};
 #pragma unroll 1
   for (int c = 0; c < 16; ++c) {
     const float* sc = src + (size_t)c * t.tot_c2 + y * L.W2 + x;
@@ -268,11 +281,15 @@ __global__ void pnet_conv3_heads_kernel(const float* __restrict__ c2, LevelTable
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const float v = sc[kh * L.W2 + kw];
+        const float2_t v2 = {v, v};
         const float* ww = w.w3 + ((c * 3 + kh) * 3 + kw) * 32;
 #pragma unroll
-        for (int co = 0; co < 32; ++co) acc[co] = fmaf(v, ww[co], acc[co]);
+        for (int j = 0; j < 16; ++j) acc2[j] = __builtin_elementwise_fma(v2, float2_t{ww[2 * j], ww[2 * j + 1]}, acc2[j]);
       }
   }
+  float acc[32];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { acc[2 * j] = acc2[j][0]; acc[2 * j + 1] = acc2[j][1]; }
   float a0 = w.b41[0], a1 = w.b41[1], r0 = w.b42[0], r1 = w.b42[1], r2 = w.b42[2], r3 = w.b42[3];
 #pragma unroll
   for (int c = 0; c < 32; ++c) {
@@ -543,8 +560,9 @@ __global__ void __launch_bounds__(256) crop_resize_kernel(const uint8_t* __restr
   const Row r = rows[(size_t)img * KEEP + k];
   const int y0 = r.y - 1, x0 = r.x - 1, ch = r.ey - y0, cw = r.ex - x0;
   float* o = d.base;
-  if (d.ps == 4)
+  if (d.ps == 4 && blockIdx.z == 0)
     for (int i = threadIdx.x; i < S * S; i += blockDim.x) o[i * 4 + 3] = 0.f;
+  if ((ch <= 0 || cw <= 0) && blockIdx.z != 0) return;
   if (ch <= 0 || cw <= 0) {
     for (int i = threadIdx.x; i < S * S; i += blockDim.x) { o[i * d.ps] = 0.f; o[i * d.ps + d.cs] = 0.f; o[i * d.ps + 2 * d.cs] = 0.f; }
     if (threadIdx.x == 0) atomicOr(status, ST_DEGENERATE);
@@ -580,7 +598,7 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
                                                                 const Row* __restrict__ rows, const int* __restrict__ row_cnt,
                                                                 int S, float* __restrict__ out, int* __restrict__ status,
                                                                 const int* __restrict__ offs, int c0, int cap) {
-  __shared__ unsigned strips[4][CROP_MAXB + 32];
+  __shared__ __attribute__((aligned(16))) unsigned strips[4][CROP_MAXB + 32];
   const int k = blockIdx.x, img = blockIdx.y;
   if (k >= row_cnt[img]) return;
   const CropDst d = crop_dst(out, offs, c0, cap, img, k, S);
@@ -588,8 +606,9 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
   const Row r = rows[(size_t)img * KEEP + k];
   const int y0 = r.y - 1, x0 = r.x - 1, ch = r.ey - y0, cw = r.ex - x0;
   float* o = d.base;
-  if (d.ps == 4)
+  if (d.ps == 4 && blockIdx.z == 0)
     for (int i = threadIdx.x; i < S * S; i += blockDim.x) o[i * 4 + 3] = 0.f;
+  if ((ch <= 0 || cw <= 0) && blockIdx.z != 0) return;
   if (ch <= 0 || cw <= 0) {
     for (int i = threadIdx.x; i < S * S; i += blockDim.x) { o[i * d.ps] = 0.f; o[i * d.ps + d.cs] = 0.f; o[i * d.ps + 2 * d.cs] = 0.f; }
     if (threadIdx.x == 0) atomicOr(status, ST_DEGENERATE);
@@ -598,6 +617,7 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rowb = W * 3, bs = x0 * 3, be = (x0 + cw) * 3;
   const int c_lo = bs >> 4, nch = ((be + 15) >> 4) - c_lo, off = bs - (c_lo << 4);
+  if (nch * 16 > CROP_MAXB + 32 && blockIdx.z != 0) return;
   if (nch * 16 > CROP_MAXB + 32) {  // wider than a strip: per-pixel path for this candidate
     const uint8_t* base = frames + ((size_t)img * H + y0) * (size_t)W * 3 + (size_t)x0 * 3;
     for (int i = threadIdx.x; i < S * S; i += blockDim.x) {
@@ -618,24 +638,73 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
   }
   const uint8_t* fbase = frames + (size_t)img * H * rowb;
   unsigned* cs = strips[wave];
-  for (int oy = wave; oy < S; oy += 4) {
+  // blockIdx.z splits the S output rows into gridDim.z groups, so one large box (its bins are tens of input rows
+  // deep) is spread over several workgroups instead of setting the duration of the whole launch
+  const int zrows = (S + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int oy_lo = (int)blockIdx.z * zrows, oy_hi = min(S, oy_lo + zrows);
+  // per-byte column sums of input rows [h0,h1) of one 16-byte chunk column: four independent loads in flight per
+  // step (clamped row + byte mask instead of a branch, so the loads are not serialised behind their predicates)
+  auto colsum = [&](int c, int h0, int h1, unsigned (&acc)[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0u;
+    const uint8_t* p0 = fbase + (size_t)y0 * rowb + ((size_t)(c_lo + c) << 4);
+    for (int yy = h0; yy < h1; yy += 4) {
+      uint4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const uint4*>(p0 + (size_t)min(yy + j, h1 - 1) * rowb);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned msk = (yy + j < h1) ? 0xFFu : 0u;
+        const unsigned wv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[d * 4 + e] += (wv[d] >> (8 * e)) & msk;
+      }
+    }
+  };
+  if (nch <= 32) {
+    // narrow crops (the common case: a 100-px box spans ~20 chunks): a wave takes R = 64/nch output rows at
+    // once, lane -> (row sub, chunk c), so the loads keep the whole wave busy
+    const int R = 64 / nch, sub = lane / nch, c = lane - sub * nch;
+    for (int oy0 = oy_lo + wave * R; oy0 < oy_hi; oy0 += 4 * R) {
+      const int oy = oy0 + sub;
+      if (sub < R && oy < oy_hi) {
+        unsigned acc[16];
+        colsum(c, (oy * ch) / S, ((oy + 1) * ch + S - 1) / S, acc);
+        uint4* dst = reinterpret_cast<uint4*>(cs + (sub * nch + c) * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = uint4{acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int q = lane; q < R * 3 * S; q += 64) {
+        const int s2 = q / (3 * S), q2 = q - s2 * 3 * S;
+        const int oy2 = oy0 + s2;
+        if (oy2 < oy_hi) {
+          const int cch = q2 / S, ox = q2 - cch * S;
+          const int h0 = (oy2 * ch) / S, h1 = ((oy2 + 1) * ch + S - 1) / S;
+          const int w0 = (ox * cw) / S, w1 = ((ox + 1) * cw + S - 1) / S;
+          const unsigned* row = cs + s2 * nch * 16 + off;
+          unsigned sum = 0;
+          for (int xx = w0; xx < w1; ++xx) sum += row[xx * 3 + cch];
+          o[(oy2 * S + ox) * d.ps + cch * d.cs] = (((float)sum / (float)(h1 - h0)) / (float)(w1 - w0) - 127.5f) * 0.0078125f;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+  for (int oy = oy_lo + wave; oy < oy_hi; oy += 4) {
     const int h0 = (oy * ch) / S, h1 = ((oy + 1) * ch + S - 1) / S;
     for (int cbase = 0; cbase < nch; cbase += 64) {
       const int c = cbase + lane;
-      unsigned acc[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] = 0u;
       if (c < nch) {
-        for (int yy = h0; yy < h1; ++yy) {
-          const uint4 v = *reinterpret_cast<const uint4*>(fbase + (size_t)(y0 + yy) * rowb + ((size_t)(c_lo + c) << 4));
-          const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+        unsigned acc[16];
+        colsum(c, h0, h1, acc);
+        uint4* dst = reinterpret_cast<uint4*>(cs + c * 16);
 #pragma unroll
-          for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[d * 4 + e] += (wv[d] >> (8 * e)) & 0xFFu;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) cs[c * 16 + j] = acc[j];
+        for (int j = 0; j < 4; ++j) dst[j] = uint4{acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1115,6 +1184,8 @@ __global__ void __launch_bounds__(256) stage3_post_kernel(const Row* __restrict_
 
 // =============================================================================================
 // host side
+constexpr int FIN_FAST = 32;  // faces per frame covered by the one-copy read-back (VNF_FIN_FAST lowers it: test hook)
+
 struct Mtcnn : HandleBase {
   vnf_mtcnn_cfg cfg;
   PNetW pw; RNetW rw; ONetW ow;
@@ -1128,12 +1199,52 @@ struct Mtcnn : HandleBase {
   Encoder *renc = nullptr, *oenc = nullptr;  // R-Net / O-Net plans on the exact-f32 MFMA core (candidates = batch)
   int r_cap = 0, o_cap = 0;
   int* offs = nullptr;                        // device: (max_batch + 1) compact-batch offsets
-  ~Mtcnn() override { delete renc; delete oenc; }
+  // final read-back: counts block + the first FIN_FAST rows of every frame packed by one kernel into `stage`,
+  // one D2H copy into pinned memory, one host synchronisation (a frame with more faces takes the 2-D copy)
+  float* stage = nullptr;
+  int* h_pin = nullptr;
+  int fin_fast = FIN_FAST;
+  int last_b = 0;  // frames of the last vnf_mtcnn_detect (vnf_mtcnn_results_device)
+  ~Mtcnn() override { delete renc; delete oenc; if (h_pin) (void)hipHostFree(h_pin); }
   size_t cap_px = 0, cap_p1 = 0, cap_c2 = 0, cap_out = 0;
   std::vector<float> h_fin;
   std::vector<int> h_cnt;
   LevelTable last_table;
 };
+
+
+// counts block (row_cnt .. status) followed by [B][FIN_FAST][15] result rows
+__global__ void pack_results_kernel(const int* __restrict__ cnt_block, int ncnt, const float* __restrict__ fin,
+                                    const int* __restrict__ fin_cnt, int B, float* __restrict__ stage) {
+  int* so = reinterpret_cast<int*>(stage);
+  for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < ncnt; i += gridDim.x * blockDim.x) so[i] = cnt_block[i];
+  float* ro = stage + ncnt;
+  const int total = B * FIN_FAST * 15;
+  for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < total; i += gridDim.x * blockDim.x) {
+    const int img = i / (FIN_FAST * 15), r = i - img * FIN_FAST * 15, k = r / 15;
+    ro[i] = k < fin_cnt[img] ? fin[(size_t)img * KEEP * 15 + r] : 0.f;
+  }
+}
+
+// device-resident copy of the last detection, frames concatenated in order (the host arrays' layout)
+__global__ void results_device_kernel(const float* __restrict__ fin, const int* __restrict__ fin_cnt, int max_out,
+                                      int32_t* __restrict__ fidx, float* __restrict__ boxes, float* __restrict__ probs,
+                                      float* __restrict__ points) {
+  const int img = blockIdx.x;
+  int off = 0;
+  for (int i = 0; i < img; ++i) off += fin_cnt[i];
+  const int c = fin_cnt[img];
+  for (int k = threadIdx.x; k < c; k += blockDim.x) {
+    const int o = off + k;
+    if (o >= max_out) break;
+    const float* f = fin + ((size_t)img * KEEP + k) * 15;
+    if (fidx) fidx[o] = img;
+    if (boxes) { boxes[o * 4] = f[0]; boxes[o * 4 + 1] = f[1]; boxes[o * 4 + 2] = f[2]; boxes[o * 4 + 3] = f[3]; }
+    if (probs) probs[o] = f[4];
+    if (points)
+      for (int j = 0; j < 10; ++j) points[o * 10 + j] = f[5 + j];
+  }
+}
 
 static LevelTable make_levels(int h, int w, int minsize, double factor) {
   // detect_face.py:50-60,71 in python-double arithmetic
@@ -1271,6 +1382,13 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
     m->rout = (float*)m->dalloc((size_t)B * KEEP * 5 * 4);
     m->oout = (float*)m->dalloc((size_t)B * KEEP * 15 * 4);
     m->fin = (float*)m->dalloc((size_t)B * KEEP * 15 * 4);
+    {
+      const size_t sb = ((size_t)B * 3 + 16) * 4 + (size_t)B * FIN_FAST * 15 * 4;
+      m->stage = (float*)m->dalloc(sb);
+      if (hipHostMalloc((void**)&m->h_pin, sb, hipHostMallocDefault) != hipSuccess) m->h_pin = nullptr;
+      if (!m->stage || !m->h_pin) { delete m; return fail(VNF_E_HIP, "mtcnn: read-back buffers"); }
+      if (const char* ff = getenv("VNF_FIN_FAST")) m->fin_fast = std::max(0, std::min(FIN_FAST, atoi(ff)));
+    }
     m->offs = (int*)m->dalloc((size_t)(B + 1) * 4);
     if (!m->lvl || !m->p1 || !m->c2 || !m->cand || !m->keep1 || !m->cand_cnt || !m->rows || !m->rows3 || !m->crops ||
         !m->rout || !m->oout || !m->fin || !m->pw.w1 || !m->ow.d63b) {
@@ -1310,6 +1428,7 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   if (b > cfg.max_batch || H > cfg.max_height || W > cfg.max_width) return fail(VNF_E_CAPACITY, "mtcnn: frame batch exceeds handle capacity");
   LevelTable t = make_levels(H, W, cfg.min_face_size, (double)cfg.factor);
   m->last_table = t;
+  m->last_b = 0;
   cnt.assign(b, 0);
   fin.clear();
   if (t.n == 0) return VNF_OK;  // image smaller than one cell: no detections
@@ -1342,9 +1461,10 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   hipLaunchKernelGGL(nms_image_kernel, dim3(B), dim3(256), lds_img, s, m->keep1, m->keep1_cnt, t, B, 0.7f, W, H, m->rows,
                      m->row_cnt, m->status);
   VNF_HIP(hipGetLastError());
-  std::vector<int> h(cfg.max_batch * 3 + 16);
+  const int ncnt = cfg.max_batch * 3 + 16;
+  int* const h = m->h_pin;  // pinned: the copy is a true async DMA, the only wait is the stream synchronisation
   auto read_counts = [&]() -> int {
-    VNF_HIP(hipMemcpyAsync(h.data(), m->row_cnt, h.size() * 4, hipMemcpyDeviceToHost, s));
+    VNF_HIP(hipMemcpyAsync(h, m->row_cnt, (size_t)ncnt * 4, hipMemcpyDeviceToHost, s));
     VNF_HIP(hipStreamSynchronize(s));
     const int st = h[cfg.max_batch * 3];
     if (st & (ST_OVER_SCALE | ST_OVER_IMG | ST_OVER_KEEP))
@@ -1360,7 +1480,7 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   const bool crop_fast = (W * 3) % 16 == 0 && ((reinterpret_cast<uintptr_t>(frames)) & 15) == 0;
   auto crop = [&](const Row* rws, const int* cntp, int maxc, int S, float* dst, const int* offs, int c0, int cap) {
     if (crop_fast)
-      hipLaunchKernelGGL(crop_resize_rows_kernel, dim3(maxc, B), dim3(256), 0, s, frames, H, W, rws, cntp, S, dst, m->status, offs, c0, cap);
+      hipLaunchKernelGGL(crop_resize_rows_kernel, dim3(maxc, B, 4), dim3(256), 0, s, frames, H, W, rws, cntp, S, dst, m->status, offs, c0, cap);
     else
       hipLaunchKernelGGL(crop_resize_kernel, dim3(maxc, B), dim3(256), 0, s, frames, H, W, rws, cntp, S, dst, m->status, offs, c0, cap);
   };
@@ -1408,13 +1528,26 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   }
   hipLaunchKernelGGL(stage3_post_kernel, dim3(B), dim3(256), lds_post, s, m->rows3, m->row3_cnt, m->oout, cfg.thresholds[2], 0.7f,
                      cfg.select_largest, m->fin, m->fin_cnt, m->status);
+  m->last_b = B;
+  hipLaunchKernelGGL(pack_results_kernel, dim3(B), dim3(256), 0, s, m->row_cnt, ncnt, m->fin, m->fin_cnt, B, m->stage);
   VNF_HIP(hipGetLastError());
-  r = read_counts();
-  if (r != VNF_OK) return r;
+  VNF_HIP(hipMemcpyAsync(h, m->stage, ((size_t)ncnt + (size_t)B * FIN_FAST * 15) * 4, hipMemcpyDeviceToHost, s));
+  VNF_HIP(hipStreamSynchronize(s));
+  {
+    const int st = h[cfg.max_batch * 3];
+    if (st & (ST_OVER_SCALE | ST_OVER_IMG | ST_OVER_KEEP))
+      return fail(VNF_E_CAPACITY, "mtcnn: candidate table overflow (status " + std::to_string(st) + ")");
+  }
   int maxf = 0;
   for (int i = 0; i < B; ++i) { cnt[i] = h[2 * cfg.max_batch + i]; maxf = std::max(maxf, cnt[i]); }
   if (maxf == 0) return VNF_OK;
   fin.resize((size_t)B * maxf * 15);
+  if (maxf <= m->fin_fast) {
+    const float* rows = reinterpret_cast<const float*>(h + ncnt);
+    for (int i = 0; i < B; ++i)
+      memcpy(&fin[(size_t)i * maxf * 15], rows + (size_t)i * FIN_FAST * 15, (size_t)maxf * 15 * 4);
+    return VNF_OK;
+  }
   VNF_HIP(hipMemcpy2DAsync(fin.data(), (size_t)maxf * 15 * 4, m->fin, (size_t)KEEP * 15 * 4, (size_t)maxf * 15 * 4, B,
                            hipMemcpyDeviceToHost, s));
   VNF_HIP(hipStreamSynchronize(s));
@@ -1448,6 +1581,19 @@ extern "C" int vnf_mtcnn_detect(vnf_handle h, const uint8_t* frames, int b, int 
   } catch (const std::exception& ex) {
     return fail(VNF_E_INVALID, std::string("exception: ") + ex.what());
   }
+}
+
+extern "C" int vnf_mtcnn_results_device(vnf_handle h, int32_t* frame_idx, float* boxes, float* probs, float* points,
+                                        int max_out, void* stream) {
+  HandleBase* hb = reinterpret_cast<HandleBase*>(h);
+  if (!hb || hb->kind != 3) return fail(VNF_E_INVALID, "not an MTCNN handle");
+  Mtcnn* m = static_cast<Mtcnn*>(hb);
+  if (max_out < 0) return fail(VNF_E_INVALID, "vnf_mtcnn_results_device: bad argument");
+  if (m->last_b == 0 || max_out == 0) return VNF_OK;  // the last detection found nothing
+  hipLaunchKernelGGL(results_device_kernel, dim3(m->last_b), dim3(64), 0, (hipStream_t)stream, m->fin, m->fin_cnt, max_out,
+                     frame_idx, boxes, probs, points);
+  VNF_HIP(hipGetLastError());
+  return VNF_OK;
 }
 
 // Staged-parity hook: dense P-Net maps of one pyramid level for frame 0 of a batch (test use).

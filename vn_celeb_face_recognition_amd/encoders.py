@@ -144,6 +144,10 @@ class _Encoder:
                                          ctypes.c_void_p(out[n0:].data_ptr()), _lib.current_stream_ptr()))
         return out
 
+    def set_streams(self, max_streams):
+        """Cap the encoder's internal batch split (vnf_encoder_set_streams): 1 when other work shares the GPU."""
+        _lib.check(_lib.load().vnf_encoder_set_streams(self._ensure_handle(), int(max_streams)))
+
     # ---- extras used by tests / bench
     def tap(self, name, n):
         """Copy an internal activation of the last forward (first n images) to a (n,C,H,W) fp32 array."""
