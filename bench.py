@@ -283,7 +283,8 @@ def main():
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_note": "HBM bytes per step, FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE from separate "
                                          "rocprofv3 --pmc passes (profiles/r01_traffic.json); algorithmic floor 87 MB",
-                         "kernel": "conv_igemm_dma_kernel (all launches of one embed step; device time by HIP events)",
+                         "kernel": "implicit-GEMM convolution kernels conv_igemm_dma / conv_patch / conv_igemm_ws (every launch of one "
+                                   "embed step, tile configuration per layer chosen by the create-time autotuner; device time by HIP events)",
                          "flop_per_step_algorithmic": flop_per_step,
                          "flop_per_image_executed": executed, "flop_per_image_counted_by_engine": alg,
                          "device_ms_per_step": round(dev_ms / args.steps, 4)},

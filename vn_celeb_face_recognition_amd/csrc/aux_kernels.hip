@@ -56,6 +56,70 @@ hipError_t launch_pack_input(const void* x, int x_dtype, void* out, int dtype, i
   return hipErrorInvalidValue;
 }
 
+// ---------------------------------------------------------------- IRv1 stem: NCHW input -> conv2d_1a, direct
+// inception_resnet_v1.py:281 (BasicConv2d 3->32, 3x3 stride 2, folded BN, ReLU) straight from the caller's NCHW
+// tensor: no NHWC8 staging pass (it wrote and re-read 105 MB per 256 images) and no 3->8 channel padding in an
+// MFMA K of 72 that is 62 % zeros.  One thread per output pixel, 32 channels as 16 packed-FMA pairs in the
+// reference's (c,kh,kw) order, fp32 weights [27][32] read as wave-uniform scalars, one 64/128-byte NHWC row out.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) stem_conv1a_kernel(const TI* __restrict__ x, TO* __restrict__ y, int ldy, int n,
+                                                          const float* __restrict__ wt) {
+  constexpr int S = 160, SO = 79;
+  const unsigned total = (unsigned)n * SO * SO;
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const unsigned img = i / (SO * SO), p = i - img * (SO * SO);
+  const int oy = (int)(p / SO), ox = (int)(p - (unsigned)oy * SO);
+  const TI* src = x + (size_t)img * 3 * S * S + (size_t)(2 * oy) * S + 2 * ox;
+  float in[27];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) in[(c * 3 + kh) * 3 + kw] = to_f(src[(size_t)c * S * S + kh * S + kw]);
+  f2_t acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = f2_t{wt[27 * 32 + 2 * j], wt[27 * 32 + 2 * j + 1]};
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const f2_t v2 = {in[k], in[k]};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = __builtin_elementwise_fma(v2, f2_t{wt[k * 32 + 2 * j], wt[k * 32 + 2 * j + 1]}, acc[j]);
+  }
+  TO o[32];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { o[2 * j] = (TO)fmaxf(acc[j][0], 0.f); o[2 * j + 1] = (TO)fmaxf(acc[j][1], 0.f); }
+  uint4* dst = reinterpret_cast<uint4*>(y + (size_t)i * ldy);
+#pragma unroll
+  for (int q = 0; q < (int)(32 * sizeof(TO) / 16); ++q) dst[q] = reinterpret_cast<const uint4*>(o)[q];
+}
+
+template <typename TI>
+static hipError_t stem_dispatch_out(const void* x, void* y, int ldy, int dtype, int n, const float* wt, hipStream_t s) {
+  const unsigned total = (unsigned)n * 79 * 79;
+  const int blocks = (int)((total + 255) / 256);
+  if (blocks == 0) return hipSuccess;
+  switch (dtype) {
+    case BF16: hipLaunchKernelGGL((stem_conv1a_kernel<TI, __bf16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (__bf16*)y, ldy, n, wt); break;
+    case F16: hipLaunchKernelGGL((stem_conv1a_kernel<TI, _Float16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (_Float16*)y, ldy, n, wt); break;
+    case F32: hipLaunchKernelGGL((stem_conv1a_kernel<TI, float>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (float*)y, ldy, n, wt); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_stem_conv1a(const void* x, int x_dtype, void* y, int ldy, int dtype, int n, const float* wt, hipStream_t s) {
+  switch (x_dtype) {
+    case F32: return stem_dispatch_out<float>(x, y, ldy, dtype, n, wt, s);
+    case BF16: return stem_dispatch_out<__bf16>(x, y, ldy, dtype, n, wt, s);
+    case F16: return stem_dispatch_out<_Float16>(x, y, ldy, dtype, n, wt, s);
+  }
+  return hipErrorInvalidValue;
+}
+
 // ---------------------------------------------------------------- max pool 3x3 stride 2
 template <typename T>
 __global__ void maxpool3s2_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int n, int H, int W,

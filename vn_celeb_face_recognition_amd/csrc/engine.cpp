@@ -435,6 +435,24 @@ int build_irv1(Encoder& e, WeightMap& wm) {
 
   // ---- stem (inception_resnet_v1.py:281-287)
   TRY(simple("conv2d_1a", b_in, 0, 3, 8, 32, 3, 3, 2, 0, 0, b_1a, 0));
+  {
+    // the first convolution runs as a direct kernel on the caller's NCHW tensor (aux_kernels.hip): the layer stays
+    // in `convs` for the FLOP accounting, the PACK + CONV pair of ops becomes one STEM1 op
+    static const int direct = getenv("VNF_DIRECT_STEM") ? atoi(getenv("VNF_DIRECT_STEM")) : 1;
+    Piece pc;
+    if (direct && basic_piece(wm, "conv2d_1a", 3, 32, 3, 3, pc)) {
+      std::vector<float> wt(27 * 32 + 32);
+      for (int co = 0; co < 32; ++co) {
+        for (int k = 0; k < 27; ++k) wt[k * 32 + co] = pc.w[co * 27 + k] * pc.scale[co];
+        wt[27 * 32 + co] = pc.bias[co];
+      }
+      e.stem_wt = (float*)e.upload(wt.data(), wt.size() * 4);
+      if (!e.stem_wt) return VNF_E_HIP;
+      e.ops.resize(e.ops.size() - 2);
+      Op op; op.kind = Op::STEM1; op.a = (int)e.convs.size() - 1; op.b = b_1a;
+      e.ops.push_back(op);
+    }
+  }
   TRY(simple("conv2d_2a", b_1a, 0, 32, 32, 32, 3, 3, 1, 0, 0, b_2a, 0));
   TRY(simple("conv2d_2b", b_2a, 0, 32, 32, 64, 3, 3, 1, 1, 1, b_2b, 0));
   add_maxpool(e, b_2b, b_3a, 0);
@@ -842,6 +860,13 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
             if (err != hipSuccess) return fail(VNF_E_HIP, L.name + ": " + hipGetErrorString(err));
             break;
           }
+          case Op::STEM1: {
+            const Buf& ob = bufs[op.b];
+            const char* src = (const char*)x + (size_t)n0 * 3 * in_size * in_size * xes;
+            VNF_HIP(launch_stem_conv1a(src, x_dtype, ob.ptr + (size_t)n0 * ob.elems_per_image() * es, ob.C, dtype, nn,
+                                       stem_wt, s));
+            break;
+          }
           case Op::MAXPOOL: {
             const Buf& ib = bufs[op.a];
             const Buf& ob = bufs[op.b];
@@ -900,8 +925,12 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
         const double gf = 2.0 * L.macs_alg * n / 1e9;
         snprintf(line, sizeof line, "%-28s conv M/img=%-6d N=%-5d K=%-5d %dx%d s%d cfg%-2d %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n",
                  L.name.c_str(), L.Ho * L.Wo, L.cout, L.K, L.KH, L.KW, L.sh, L.cfg, ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
+      } else if (op.kind == Op::STEM1) {
+        const double gf = 2.0 * convs[op.a].macs_alg * n / 1e9;
+        snprintf(line, sizeof line, "%-28s %-60s %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n", "conv2d_1a (direct, NCHW in)",
+                 "3x3 s2 3->32 on the caller's tensor, VALU packed FMA", ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
       } else {
-        static const char* kn[] = {"pack", "conv", "maxpool", "avgpool", "l2norm", "copyout", "maxpool_ceil"};
+        static const char* kn[] = {"pack", "conv", "maxpool", "avgpool", "l2norm", "copyout", "maxpool_ceil", "stem1"};
         snprintf(line, sizeof line, "%-28s %-8s %60s %8.4f ms\n", "", kn[op.kind], "", ms[oi]);
       }
       *report += line;

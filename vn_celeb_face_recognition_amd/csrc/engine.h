@@ -69,7 +69,7 @@ struct ConvLayer {
 };
 
 struct Op {
-  enum Kind { PACK, CONV, MAXPOOL, AVGPOOL, L2NORM, COPYOUT, MAXPOOLC } kind;
+  enum Kind { PACK, CONV, MAXPOOL, AVGPOOL, L2NORM, COPYOUT, MAXPOOLC, STEM1 } kind;
   int a = 0, b = 0, c = 0, d = 0, e = 0;  // meaning per kind (see engine.cpp)
 };
 
@@ -93,6 +93,7 @@ struct Encoder : HandleBase {
   ConvArgs conv_args(const ConvLayer& L, int n0, int nn) const;
   int run(const void* x, int n, int x_dtype, float* out, hipStream_t s, std::string* report = nullptr);
   int run_range(const void* x, int i0, int i1, int x_dtype, float* out, hipStream_t s, std::string* report);
+  float* stem_wt = nullptr;  // IRv1: fp32 folded conv2d_1a weights + biases for the direct stem kernel (Op::STEM1)
   int max_streams = 4;  // cap on run()'s batch split (1: never fork side streams)
   int tune_batch = 0;   // batch size the autotuner times at (0: the part size run() uses at max_batch)
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};

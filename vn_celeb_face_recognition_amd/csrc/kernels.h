@@ -50,6 +50,10 @@ bool conv_cfg_ok(const ConvArgs& a, int cfg);  // is tile configuration `cfg` us
 // NCHW (n,3,S,S) of x_dtype -> NHWC8 of dtype (channels 3..7 zero)
 hipError_t launch_pack_input(const void* x, int x_dtype, void* out, int dtype, int n, int hw, hipStream_t s);
 
+// IRv1 stem: NCHW (n,3,160,160) of x_dtype -> conv2d_1a (3x3 s2, folded BN, ReLU) NHWC (n,79,79,32) of dtype;
+// wt = fp32 [27][32] folded weights (k = (c*3+kh)*3+kw) followed by 32 biases
+hipError_t launch_stem_conv1a(const void* x, int x_dtype, void* y, int ldy, int dtype, int n, const float* wt, hipStream_t s);
+
 // 3x3 stride-2 max pool, floor mode, NHWC slice -> NHWC slice
 hipError_t launch_maxpool3s2(const void* x, int ldx, void* y, int ldy, int dtype, int n, int H, int W, int C,
                              hipStream_t s);
