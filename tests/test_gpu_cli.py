@@ -146,3 +146,35 @@ def test_demo_image_and_demo_video_cli(tmp_path):
     assert lines[4].endswith(',"[]",4,"[]"')                   # the blank frame
     assert lines[1].split(",")[0] == "0.04" and '"[\'celeb_' in lines[1] or "Unknown" in lines[1]
     assert sorted(os.listdir(tmp_path / "of")) == ["frame_%d.png" % i for i in range(1, 6)]
+
+
+def test_celeb_statistic_cli(tmp_path):
+    """celeb_statistic.py end to end: -fidx sub-sampling, per-class thresholds file, tracker CSV, interval JSON; and the
+    tracker re-use branch (celeb_statistic.py:393-399) reproduces the JSON without touching the GPU."""
+    import json
+    ck, l2n = _classifier_files(tmp_path)
+    a = load_image("mrDam_HaHo_recog.jpg")
+    fd = tmp_path / "frames"; fd.mkdir()
+    from PIL import Image
+    for i in range(12):
+        Image.fromarray(a if i % 5 else np.zeros_like(a)).save(fd / ("f_%02d.png" % i))
+    thr = tmp_path / "thr.json"
+    thr.write_text(json.dumps({str(i): 0.0 for i in range(1001)}))
+    common = ["-i", str(fd), "-fps", "4", "-fidx", "1", "3", "-m", ck, "-l2n", l2n, "-enc", "InceptionResnetV1", "-eargs",
+              os.path.join(REPO, "cfg/embedding/inception_resnet_v1.json"), "-tg_fs", "160", "--inference_method",
+              "par_fd_vs_aln", "-dargs", os.path.join(REPO, "cfg/detection/mtcnn.json"), "--track_bbox",
+              "--local_thresholds", str(thr), "-tap", "2", "-nvi", "2", "--n_frames", "2",
+              "-o", str(tmp_path / "of"), "-ot", str(tmp_path / "tracker.csv"), "-jst", str(tmp_path / "t.json")]
+    out = _run([os.path.join(REPO, "celeb_statistic.py")] + common, str(tmp_path))
+    assert "Create tracker file" in out and "Using local thresholds" in out
+    rows = open(tmp_path / "tracker.csv").read().splitlines()
+    assert rows[0] == "Time,Names,Frame_idx,Bboxes"
+    # 12 frames at 4 fps: count % 4 in {1, 3} -> frames 1,3,5,7,9,11
+    assert [r.split(",")[-0].split(",")[0] for r in rows[1:]] == ["0.25", "0.75", "1.25", "1.75", "2.25", "2.75"]
+    stat = json.load(open(tmp_path / "t.json"))
+    assert list(stat) == ["1", "2"] and stat["1"]["interval"][0] == "0.0h:0.0m:0.25s"
+    assert sum(len(v) for itv in stat.values() for v in itv["celebrities"].values()) > 0
+    first = open(tmp_path / "t.json").read()
+    os.remove(tmp_path / "t.json")
+    out2 = _run([os.path.join(REPO, "celeb_statistic.py")] + common + ["--statistic_mode", "dynamic_itv"], str(tmp_path))
+    assert "Re-use tracker file" in out2 and open(tmp_path / "t.json").read() == first

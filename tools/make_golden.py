@@ -229,10 +229,58 @@ def golden_umeyama():
     print("umeyama:", params.shape, params[0])
 
 
+def golden_celeb_stat():
+    """celeb_statistic.py's interval statistics, run from the reference's own function bodies:
+    the module itself cannot be imported here (cv2 / pafy / face_alignment / imgaug are absent: ordinary
+    ModuleNotFoundError), so the three statistics functions and the two helpers they call are compiled from their
+    source text into a scratch namespace -- executed, not stored."""
+    import ast as _ast
+    import math as _math
+
+    def grab(path, names):
+        tree = _ast.parse(open(path).read())
+        keep = [n for n in tree.body if isinstance(n, _ast.FunctionDef) and n.name in names]
+        return _ast.Module(body=keep, type_ignores=[])
+
+    ns = {"ast": _ast, "math": _math, "json": json}
+    exec(compile(grab(os.path.join(REF, "utils", "utils.py"), {"convert_sec_to_max_time_quantity", "write_json"}),
+                 "ref_utils", "exec"), ns)
+    exec(compile(grab(os.path.join(REF, "celeb_statistic.py"),
+                      {"find_celeb_infor_in_interval", "export_json_stat_dynamic_itv", "export_json_stat_fixed_itv"}),
+                 "ref_celeb_statistic", "exec"), ns)
+    import pandas as pd
+    rng = np.random.default_rng(7)
+    people = ["celeb_%d" % i for i in range(6)] + ["Unknown"]
+    lines = ["Time,Names,Frame_idx,Bboxes,Emotion"]
+    t = 0.0
+    for r in range(83):
+        t += float(rng.choice([0.04, 0.2, 0.25, 1.0]))
+        k = int(rng.integers(0, 4))
+        names = [people[int(j)] for j in rng.integers(0, len(people), size=k)]
+        boxes = [[round(float(v), 6) for v in np.sort(rng.random(4))] for _ in range(k)]
+        emos = [["happy", "neutral"][: int(rng.integers(0, 3))] for _ in range(k)]
+        lines.append('%s,"%s",%d,"%s","%s"' % (repr(t), names, 1 + r * 5, boxes, emos))
+    csv_path = os.path.join(OUT, "celeb_stat_tracker.csv")
+    with open(csv_path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    df = pd.read_csv(csv_path)
+    out = {}
+    tmp = os.path.join(OUT, "_tmp_stat.json")
+    for tag, fn, arg, nap in (("dynamic_5_4", "export_json_stat_dynamic_itv", 5, 4), ("dynamic_7_2", "export_json_stat_dynamic_itv", 7, 2),
+                              ("fixed_16_3", "export_json_stat_fixed_itv", 16, 3), ("fixed_83_1", "export_json_stat_fixed_itv", 83, 1)):
+        ns[fn](df, tmp, arg, nap, "Unknown")
+        out[tag] = {"text": open(tmp).read()}
+    os.remove(tmp)
+    out["hms"] = {repr(v): ns["convert_sec_to_max_time_quantity"](v) for v in (0.0, 59.999, 61.5, 3600.0, 7325.25, 86399.99)}
+    with open(os.path.join(OUT, "celeb_stat_ref.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("celeb_stat:", {k: len(v.get("text", "")) if isinstance(v, dict) and "text" in v else len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_shim()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["irv1", "mlp", "ir100", "mtcnn", "umeyama"]
+    which = sys.argv[1:] or ["irv1", "mlp", "ir100", "mtcnn", "umeyama", "celeb_stat"]
     for w in which:
         globals()["golden_" + w]()

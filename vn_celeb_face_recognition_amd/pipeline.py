@@ -99,24 +99,27 @@ def find_embedding(image_tensor, embedding_model):
     return embeddings.detach()
 
 
+def identify_names(preds, probs, n_classes, name_df, threshold):
+    """demo_image.py:119-147 after the argmax: threshold (float, or dict str(class) -> float as in
+    celeb_statistic.py:128-136), then the first label2name row of each kept label, else 'Unknown'."""
+    preds = preds.cpu().numpy() if hasattr(preds, "cpu") else np.asarray(preds)
+    probs = probs.cpu().numpy() if hasattr(probs, "cpu") else np.asarray(probs)
+    filtered = []
+    for p, pr in zip(preds, probs):
+        thr = threshold if type(threshold) is float else threshold[str(int(p))]
+        filtered.append(int(p) if pr >= thr else n_classes)
+    first = {}
+    for l, nm in zip(list(name_df['label']), list(name_df['name'])):
+        first.setdefault(int(l), nm)
+    return [first.get(p, 'Unknown') for p in filtered]
+
+
 def identify_person(embeddings, classify_model, name_df, threshold):
     """demo_image.py:113-147.  name_df: anything with ['label'] / ['name'] columns (pandas
     DataFrame or dict of sequences)."""
     classify_model.eval()
     logp, amax, prob = classify_model.classify(embeddings, want_logp=False)
-    n_classes = classify_model.num_classes
-    preds = amax.cpu().numpy()
-    probs = prob.cpu().numpy()
-    filtered = []
-    for p, pr in zip(preds, probs):
-        thr = threshold if type(threshold) is float else threshold[str(int(p))]
-        filtered.append(int(p) if pr >= thr else n_classes)
-    labels = list(name_df['label'])
-    names = list(name_df['name'])
-    first = {}
-    for l, nm in zip(labels, names):
-        first.setdefault(int(l), nm)
-    return [first.get(p, 'Unknown') for p in filtered]
+    return identify_names(amax, prob, classify_model.num_classes, name_df, threshold)
 
 
 def recognize_celeb(bth_alg_face_list, device, emb_model, classify_model, transforms, label2name_df, threshold):
