@@ -5,8 +5,9 @@
 //   co = output channel                     -> "channel" axis, BN per workgroup
 //   k  = (kh, kw, c) flattened, c fastest  -> walked in 128-byte K tiles
 // A is never materialised: every 16-byte k-chunk (8 x 16-bit or 4 x f32 channels of one filter tap)
-// is gathered straight from the NHWC input with a per-chunk offset table (ktab); padded borders
-// and rows past M read a 16-byte zero page instead.
+// is gathered straight from the NHWC input (tap and channel of each lane's chunk are tracked
+// incrementally; the patch / wave-specialised / fallback kernels use the per-chunk offset table
+// ktab); padded borders and rows past M read a 16-byte zero page instead.
 //
 // Main kernel (conv_igemm_dma_kernel): both operands go global -> LDS by LDS-DMA
 // (global_load_lds_dwordx4, one 1-KiB piece = 8 rows x 128 B per wave instruction), never through
@@ -18,8 +19,8 @@
 // so bytes-in-flight per CU -- what bounds these small-K, small-N problems -- is set by LDS
 // capacity (160 KiB) instead of by register pressure.
 //
-// Fallback kernel (conv_igemm_kernel): register-staged double buffering, used when the gather
-// table does not fit LDS (IR-100's 25088-deep fc).
+// Fallback kernel (conv_igemm_kernel): register-staged double buffering (VNF_CONV_REG=1; the
+// first version of the core, kept as a cross-check).
 //
 // The MFMA is issued with the WEIGHT fragment as the A operand and the ACTIVATION fragment as
 // the B operand, so an accumulator register quad holds 4 consecutive output channels of one
@@ -105,10 +106,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const KArgs
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int nkt = a.nkt;
 
-  // gather table -> LDS (behind the ring), so the K loop issues no VGPR-destination global load
-  int4* sK = reinterpret_cast<int4*>(smem + S * STAGE);
-  for (int i = tid; i < nkt * 8; i += NT) sK[i] = a.ktab[i];
-
   const int lrow = tid >> 3, lcol = tid & 7;
   const int lchunk = lcol ^ (lrow & 7);  // logical k-chunk this lane fetches (physical slot = lcol)
   int abase[AP], ahi[AP], awi[AP];
@@ -121,21 +118,35 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const KArgs
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();  // gather table visible
 
+  // This lane's k-chunk of the next K tile to issue, as (tap row, tap column, channel): advanced by one K tile per
+  // issue() -- issue() is called with consecutive kt -- instead of looked up in the layer's gather table, so the
+  // prologue has no table load and no barrier before the first DMA (the table's round trip was ~1.5 k cycles of
+  // every workgroup; most launches of the inception blocks only live ~10 k).
+  int g_c = lchunk * CH, g_kh = 0, g_kw = 0;
+  auto g_norm = [&]() {
+    while (g_c >= a.Cin) {
+      g_c -= a.Cin;
+      if (++g_kw == a.KW) { g_kw = 0; ++g_kh; }
+    }
+  };
+  g_norm();
   auto issue = [&](int kt) {
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((kt % S) * STAGE) + (unsigned)(wave * 1024));
-    const int4 e = sK[kt * 8 + lchunk];
+    const bool kvalid = g_kh < a.KH;  // k < K
+    const int ex = (g_kh * a.W + g_kw) * a.ldx + g_c;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const int hi = ahi[p] + e.y, wi = awi[p] + e.z;
-      const bool ok = e.w && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-      const char* src = ok ? a.x + (size_t)(abase[p] + e.x) * ES : a.zero;
+      const int hi = ahi[p] + g_kh, wi = awi[p] + g_kw;
+      const bool ok = kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      const char* src = ok ? a.x + (size_t)(abase[p] + ex) * ES : a.zero;
       glds16(src, sbase + p * (NW * 1024));
     }
 #pragma unroll
     for (int p = 0; p < BP; ++p)
       glds16(wsrc + ((size_t)(RS * p) * a.Kpad + (size_t)kt * BKE) * ES, sbase + BM * 128 + p * (NW * 1024));
+    g_c += BKE;
+    g_norm();
   };
 
 #pragma unroll
@@ -275,7 +286,7 @@ static hipError_t launch_dma(const KArgs& k, hipStream_t s) {
   constexpr int ring = S * (BM + BN) * 128;
   static bool attr_done = false;
   KArgs kk = k;
-  const int lds = ring + k.nkt * 8 * 16;
+  const int lds = ring;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN, WM, WN, S>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -329,12 +340,12 @@ static bool dma_capable(const ConvArgs& a) { return (a.Kpad / (128 / dtype_size(
 bool conv_cfg_ok(const ConvArgs& a, int cfg) {
   if (cfg >= kNumCfgs + patch_num_cfgs()) return dma_capable(a) && ws_cfg_ok(a, cfg - kNumCfgs - patch_num_cfgs());
   if (cfg >= kNumCfgs) return dma_capable(a) && patch_cfg_ok(a, cfg - kNumCfgs);
-  if (cfg < 0 || !dma_capable(a)) return false;
+  if (cfg < 0) return false;  // the ring kernel needs no table in LDS: any K
   const TileCfg& c = kCfgs[cfg];
   if (c.bn > 32 && a.Cout <= c.bn / 2) return false;  // more than half the tile would be padding
   if (((a.Cout + c.bn - 1) / c.bn) * c.bn > a.cout_pad) return false;  // weight rows n0..n0+BN-1 must exist in the packed buffer
   if ((c.bn % 64) && a.Cout % c.bn) return false;      // 96/192-wide tiles only where they divide N
-  const int lds = c.s * (c.bm + c.bn) * 128 + (a.Kpad / (128 / dtype_size(a.dtype))) * 8 * 16;
+  const int lds = c.s * (c.bm + c.bn) * 128;  // the ring (and, after the K loop, the epilogue staging)
   return lds <= 160 * 1024;
 }
 
@@ -396,7 +407,7 @@ static hipError_t launch_typed(const ConvArgs& a, const KArgs& k, hipStream_t s)
   while (bn > 64 && blocks(128, bn) < 512) bn >>= 1;
   int bm = 128;
   if (bn <= 64 && blocks(128, bn) < 512) bm = 64;
-  if (!env_reg && k.zero && dma_capable(a)) {
+  if (!env_reg && k.zero) {
     const int id = bm == 128 ? (bn == 128 ? 0 : bn == 64 ? 1 : 2) : (bn == 64 ? 3 : 4);
     return launch_cfg<T>(id, k, s);
   }
