@@ -99,6 +99,13 @@ int vnf_encoder_flops(vnf_handle h, double* algorithmic, double* executed);
  * stream) sets 1: the forks then only take turns with that work.  Default 4 = the library decides. */
 int vnf_encoder_set_streams(vnf_handle h, int max_streams);
 
+/* Throughput mode for streams of independent batches (find_embedding.py's directory walk, the benchmark loop):
+ * consecutive vnf_embed calls rotate over n (1..4) private activation-buffer sets, so calls the caller issues on
+ * DIFFERENT streams overlap on the GPU; a set is re-used only after the event recorded at its previous use.
+ * Each call stays ordered on the stream it was given.  Extra sets are allocated at first use (~2 GB for IRv1 at
+ * max_batch 256).  Default 1. */
+int vnf_encoder_set_contexts(vnf_handle h, int n);
+
 /* classifier ------------------------------------------------------------------------------- */
 int vnf_mlp_create(const vnf_tensor_desc* weights, int n_weights, int input_dim, int num_classes,
                    int max_batch, vnf_handle* out);

@@ -111,7 +111,8 @@ def test_face_pipeline_submit_overlaps_without_changing_results(tmp_path):
     det2 = models.MTCNN(keep_all=True, min_face_size=40, device=dev, max_batch=2, max_height=360, max_width=640)
     pipe2 = FacePipeline([det, det2], enc, clf, pipe.label2name, 160, 0.0)   # two detection threads + streams
     pipe3 = FacePipeline(det, enc, clf, pipe.label2name, 160, 0.0, embed_batch=8)    # faces of several submits embedded together
-    for p in (pipe, pipe2, pipe3):
+    pipe4 = FacePipeline(det, enc, clf, pipe.label2name, 160, 0.0, embed_batch=8, embed_lanes=2)   # ... on rotating streams
+    for p in (pipe, pipe2, pipe3, pipe4):
         for rep in range(3):
             tickets = [p.submit(b) for b in batches]          # all three in flight before any result is read
             for t, w in zip(tickets, want):

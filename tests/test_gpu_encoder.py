@@ -132,3 +132,29 @@ def test_ir100_stage_taps_and_bf16(irv1_sd):
     assert rel.max() <= 5e-2
     cos = (yb * ref).sum(axis=1) / np.linalg.norm(yb, axis=1) / np.linalg.norm(ref, axis=1)
     assert cos.min() >= 0.998
+
+
+def test_activation_contexts_let_calls_on_different_streams_overlap_without_changing_results():
+    """vnf_encoder_set_contexts: consecutive calls rotate over private activation-buffer sets, so batches issued on
+    different streams run concurrently; every embedding must equal the one-stream, one-context result bit for bit."""
+    import torch
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    dev = torch.device("cuda:0")
+    m = InceptionResnetV1(pretrained=None, device=dev, compute_dtype="bf16", max_batch=24).eval()
+    xs = [torch.randn((24 - 5 * i, 3, 160, 160), generator=torch.Generator().manual_seed(10 + i)).to(dev).to(torch.bfloat16)
+          for i in range(3)]
+    want = [m(x).cpu().numpy() for x in xs]
+    m.set_streams(1)
+    m.set_contexts(2)
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(4):
+        for i, x in enumerate(xs):
+            with torch.cuda.stream(lanes[(rep * 3 + i) % 2]):
+                outs.append((i, m(x)))
+    torch.cuda.synchronize()
+    for i, o in outs:
+        assert np.array_equal(o.cpu().numpy(), want[i])
+    m.set_contexts(1)
+    assert np.array_equal(m(xs[0]).cpu().numpy(), want[0])

@@ -43,6 +43,7 @@ SIGNATURES = {
     "vnf_encoder_profile": (_I, [_P, _P, _I, _I, _P, _P, ctypes.c_char_p, ctypes.c_int64]),
     "vnf_encoder_flops": (_I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "vnf_encoder_set_streams": (_I, [_P, _I]),
+    "vnf_encoder_set_contexts": (_I, [_P, _I]),
     "vnf_mlp_create": (_I, [ctypes.POINTER(TensorDesc), _I, _I, _I, _I, ctypes.POINTER(_P)]),
     "vnf_classify": (_I, [_P, _P, _I, _P, _P, _P, _P]),
     "vnf_mtcnn_create": (_I, [ctypes.POINTER(TensorDesc), _I, ctypes.POINTER(TensorDesc), _I,

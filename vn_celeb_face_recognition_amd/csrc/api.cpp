@@ -135,7 +135,21 @@ int vnf_encoder_set_streams(vnf_handle h, int max_streams) {
   Encoder* e = as_encoder(h);
   if (!e) return fail(VNF_E_INVALID, "not an encoder handle");
   if (max_streams < 1 || max_streams > 4) return fail(VNF_E_INVALID, "vnf_encoder_set_streams: 1..4");
-  e->max_streams = max_streams;
+  if (e->max_streams != max_streams) {
+    e->max_streams = max_streams;
+    return e->autotune();  // the part size the layers see changed: pick the tiles again
+  }
+  return VNF_OK;
+  API_GUARD_END
+}
+
+int vnf_encoder_set_contexts(vnf_handle h, int n) {
+  API_GUARD_BEGIN
+  Encoder* e = as_encoder(h);
+  if (!e) return fail(VNF_E_INVALID, "not an encoder handle");
+  if (n < 1 || n > 4) return fail(VNF_E_INVALID, "vnf_encoder_set_contexts: 1..4");
+  e->n_ctx = n;
+  e->next_ctx = 0;
   return VNF_OK;
   API_GUARD_END
 }

@@ -798,9 +798,54 @@ int build_onet(Encoder& e, WeightMap& wm) {
 // concurrently on side streams (fork / join with events on the caller's stream): the small late
 // layers (a few hundred workgroups, latency-bound) of one part fill the CUs the other leaves idle,
 // and kernel-boundary drains overlap.
+int Encoder::select_ctx(hipStream_t s, int* used) {
+  const int es = dtype_size(dtype);
+  if (ctx_bufs.empty()) {  // context 0 = the buffers finalize() allocated
+    ctx_bufs.emplace_back();
+    for (auto& b : bufs) ctx_bufs[0].push_back(b.ptr);
+    ctx_emb.push_back(emb_raw);
+    ctx_ev.push_back(nullptr);
+  }
+  const int c = next_ctx % n_ctx;
+  next_ctx = (c + 1) % n_ctx;
+  while ((int)ctx_bufs.size() <= c) {
+    std::vector<char*> set;
+    for (auto& b : bufs) {
+      const size_t bytes = b.elems_per_image() * es * (size_t)max_batch;
+      char* p = (char*)dalloc(bytes);
+      if (!p) return VNF_E_HIP;
+      VNF_HIP(hipMemset(p, 0, bytes));
+      set.push_back(p);
+    }
+    float* er = (float*)dalloc((size_t)max_batch * 512 * 4);
+    if (!er) return VNF_E_HIP;
+    ctx_bufs.push_back(set);
+    ctx_emb.push_back(er);
+    ctx_ev.push_back(nullptr);
+  }
+  for (size_t i = 0; i < bufs.size(); ++i) bufs[i].ptr = ctx_bufs[c][i];
+  emb_raw = ctx_emb[c];
+  if (ctx_ev[c]) VNF_HIP(hipStreamWaitEvent(s, ctx_ev[c], 0));
+  *used = c;
+  return VNF_OK;
+}
+
 int Encoder::run(const void* x, int n, int x_dtype, float* out, hipStream_t s, std::string* report) {
   if (n < 0 || n > max_batch) return fail(VNF_E_CAPACITY, "batch exceeds max_batch");
   if (n == 0) return VNF_OK;
+  if (n_ctx > 1) {
+    int c = 0;
+    int rc = select_ctx(s, &c);
+    if (rc != VNF_OK) return rc;
+    const int keep = n_ctx;
+    n_ctx = 1;  // the body below runs once on the selected set
+    rc = run(x, n, x_dtype, out, s, report);
+    n_ctx = keep;
+    if (rc != VNF_OK) return rc;
+    if (!ctx_ev[c]) VNF_HIP(hipEventCreateWithFlags(&ctx_ev[c], hipEventDisableTiming));
+    VNF_HIP(hipEventRecord(ctx_ev[c], s));
+    return VNF_OK;
+  }
   static const int env_streams = getenv("VNF_STREAMS") ? atoi(getenv("VNF_STREAMS")) : 2;
   int ns = env_streams < 1 ? 1 : (env_streams > 4 ? 4 : env_streams);
   if (ns > max_streams) ns = max_streams;

@@ -94,6 +94,14 @@ struct Encoder : HandleBase {
   int run(const void* x, int n, int x_dtype, float* out, hipStream_t s, std::string* report = nullptr);
   int run_range(const void* x, int i0, int i1, int x_dtype, float* out, hipStream_t s, std::string* report);
   float* stem_wt = nullptr;  // IRv1: fp32 folded conv2d_1a weights + biases for the direct stem kernel (Op::STEM1)
+  // activation-buffer contexts: consecutive vnf_embed calls rotate over n_ctx private buffer sets, so calls issued
+  // on DIFFERENT streams may overlap on the GPU (the latency-bound tail of one batch under the throughput-bound
+  // stem of the next); a set is re-used only after the event of its previous use.  Extra sets are allocated lazily.
+  int n_ctx = 1, next_ctx = 0;
+  std::vector<std::vector<char*>> ctx_bufs;
+  std::vector<float*> ctx_emb;
+  std::vector<hipEvent_t> ctx_ev;
+  int select_ctx(hipStream_t s, int* used);
   int max_streams = 4;  // cap on run()'s batch split (1: never fork side streams)
   int tune_batch = 0;   // batch size the autotuner times at (0: the part size run() uses at max_batch)
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};

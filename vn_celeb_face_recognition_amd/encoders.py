@@ -148,6 +148,11 @@ class _Encoder:
         """Cap the encoder's internal batch split (vnf_encoder_set_streams): 1 when other work shares the GPU."""
         _lib.check(_lib.load().vnf_encoder_set_streams(self._ensure_handle(), int(max_streams)))
 
+    def set_contexts(self, n):
+        """Rotate consecutive calls over n private activation-buffer sets (vnf_encoder_set_contexts), so calls issued
+        on different streams overlap on the GPU."""
+        _lib.check(_lib.load().vnf_encoder_set_contexts(self._ensure_handle(), int(n)))
+
     # ---- extras used by tests / bench
     def tap(self, name, n):
         """Copy an internal activation of the last forward (first n images) to a (n,C,H,W) fp32 array."""

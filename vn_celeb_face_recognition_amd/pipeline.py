@@ -180,7 +180,7 @@ class FacePipeline:
     normalised NCHW batch straight in the encoder's input dtype, and only names, boxes and
     (optionally) embeddings come back."""
 
-    def __init__(self, detector, encoder, classifier, label2name, target_size, threshold=0.0, embed_batch=0):
+    def __init__(self, detector, encoder, classifier, label2name, target_size, threshold=0.0, embed_batch=0, embed_lanes=1):
         self.detectors = list(detector) if isinstance(detector, (list, tuple)) else [detector]
         self.detector, self.encoder, self.classifier = self.detectors[0], encoder, classifier
         self.label2name = label2name
@@ -196,6 +196,10 @@ class FacePipeline:
         # waiting (0: every batch at once).  The encoder's launches have a fixed latency cost, so 256 faces cost
         # 1.4x what 128 do, not 2x.
         self.embed_batch = int(embed_batch)
+        # embedding streams that consecutive embed launches rotate over (with as many encoder activation contexts),
+        # so one group's latency-bound tail runs under the next group's stem
+        self.embed_lanes = max(1, int(embed_lanes))
+        self._lane = 0
         self._acc = None
         self._acc_n = 0
         self._pending = []
@@ -229,7 +233,7 @@ class FacePipeline:
         frames_dev.record_stream(det_s)
         if n:
             with self._enc_lock:
-                emb_s = self._emb_stream
+                emb_s = self._emb_stream = self._emb_streams[self._lane]
                 emb_s.wait_event(ready)
                 emb_s.wait_event(found)
                 with torch.cuda.stream(emb_s):
@@ -240,19 +244,26 @@ class FacePipeline:
                         if classify:
                             _, t.amax, t.prob = self.classifier.classify(t.emb, want_logp=False)
                         t.event = emb_s.record_event()
+                        self._lane = (self._lane + 1) % self.embed_lanes
                     else:
                         cap = max(self.embed_batch, n)
-                        if self._acc is None or self._acc.shape[0] < cap:
-                            self._flush_locked()
-                            self._acc = torch.empty((cap, 3, self.size, self.size), dtype=self.in_dtype, device=dev)
-                        if self._acc_n + n > self._acc.shape[0]:
-                            self._flush_locked()
-                        align_faces_device(frames_dev, fidx_d, boxes_d, points_d, self.template, self.size, want_u8=False,
-                                           out_norm=self._acc[self._acc_n:self._acc_n + n])
+                        if self._acc_n + n > cap:
+                            self._flush_locked()      # moves on to the next lane
+                            emb_s = self._emb_stream
+                            emb_s.wait_event(ready)
+                            emb_s.wait_event(found)
+                        with torch.cuda.stream(emb_s):
+                            acc = self._acc[self._lane]
+                            if acc is None or acc.shape[0] < cap:
+                                acc = self._acc[self._lane] = torch.empty((cap, 3, self.size, self.size),
+                                                                             dtype=self.in_dtype, device=dev)
+                            align_faces_device(frames_dev, fidx_d, boxes_d, points_d, self.template, self.size,
+                                               want_u8=False, out_norm=acc[self._acc_n:self._acc_n + n])
                         t._slice, t._pipe = (self._acc_n, n), self
                         self._pending.append(t)
                         self._acc_n += n
                         self._classify = classify
+                        frames_dev.record_stream(emb_s)
                         if self._acc_n >= self.embed_batch:
                             self._flush_locked()
                 for x in (frames_dev, fidx_d, boxes_d, points_d):
@@ -261,15 +272,17 @@ class FacePipeline:
             t.emb = torch.empty((0, 512), dtype=torch.float32, device=dev)
 
     def _flush_locked(self):
-        """embed (+ classify) the waiting faces on the embedding stream; caller holds the encoder lock"""
+        """embed (+ classify) the waiting faces on the current lane's stream, then move to the next lane; caller holds
+        the encoder lock"""
         if not self._pending:
             return
-        with torch.cuda.stream(self._emb_stream):
-            emb = self.encoder(self._acc[:self._acc_n])
+        emb_s = self._emb_streams[self._lane]
+        with torch.cuda.stream(emb_s):
+            emb = self.encoder(self._acc[self._lane][:self._acc_n])
             amax = prob = None
             if self._classify:
                 _, amax, prob = self.classifier.classify(emb, want_logp=False)
-            ev = self._emb_stream.record_event()
+            ev = emb_s.record_event()
         for t in self._pending:
             o, k = t._slice
             t.emb = emb[o:o + k]
@@ -277,6 +290,8 @@ class FacePipeline:
                 t.amax, t.prob = amax[o:o + k], prob[o:o + k]
             t.event = ev
         self._pending, self._acc_n = [], 0
+        self._lane = (self._lane + 1) % self.embed_lanes
+        self._emb_stream = self._emb_streams[self._lane]
 
     def flush(self):
         """Embed whatever faces are still waiting for a full embed batch (end of stream)."""
@@ -308,9 +323,13 @@ class FacePipeline:
         dev = frames_dev.device
         if self._det_streams is None:
             self._det_streams = [torch.cuda.Stream(device=dev) for _ in self.detectors]
-            self._emb_stream = torch.cuda.Stream(device=dev)
+            self._emb_streams = [torch.cuda.Stream(device=dev) for _ in range(self.embed_lanes)]
+            self._emb_stream = self._emb_streams[0]
+            self._acc = [None] * self.embed_lanes
             if hasattr(self.encoder, "set_streams"):
                 self.encoder.set_streams(1)   # the detection stream fills the gaps the encoder's own forks would
+                if self.embed_lanes > 1:
+                    self.encoder.set_contexts(self.embed_lanes)
             if len(self.detectors) > 1:
                 import queue
                 self._queues = [queue.Queue() for _ in self.detectors]
