@@ -150,6 +150,10 @@ int vnf_encoder_set_contexts(vnf_handle h, int n) {
   if (n < 1 || n > 4) return fail(VNF_E_INVALID, "vnf_encoder_set_contexts: 1..4");
   e->n_ctx = n;
   e->next_ctx = 0;
+  if (e->tune_lanes != n) {
+    e->tune_lanes = n;
+    return e->autotune();  // pick the tiles for `n` kernels sharing the GPU
+  }
   return VNF_OK;
   API_GUARD_END
 }

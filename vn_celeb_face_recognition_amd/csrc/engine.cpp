@@ -144,6 +144,18 @@ int Encoder::autotune() {
   hipEvent_t e0, e1;
   VNF_HIP(hipEventCreate(&e0));
   VNF_HIP(hipEventCreate(&e1));
+  // tune_lanes > 1: every candidate is timed as `tune_lanes` concurrent copies on separate streams -- the state the
+  // layer actually runs in when independent batches overlap (activation contexts): alone on the GPU a small tile with
+  // many workgroups looks best, beside other kernels the tile that moves fewer bytes per FLOP does
+  static const int env_lanes = getenv("VNF_TUNE_LANES") ? atoi(getenv("VNF_TUNE_LANES")) : 0;
+  const int lanes = env_lanes > 0 ? (env_lanes > 4 ? 4 : env_lanes) : (tune_lanes < 1 ? 1 : tune_lanes);
+  hipStream_t lane_s[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t lane_e[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (lanes > 1)
+    for (int l = 0; l < lanes; ++l) {
+      VNF_HIP(hipStreamCreateWithFlags(&lane_s[l], hipStreamNonBlocking));
+      VNF_HIP(hipEventCreate(&lane_e[l]));
+    }
   for (const Group& g : groups) {
     int part = (max_batch >= 192 && max_streams > 1) ? (max_batch + 1) / 2 : max_batch;  // run() cuts the batch over 2 streams
     if (tune_batch > 0 && tune_batch < part) part = tune_batch;
@@ -154,8 +166,8 @@ int Encoder::autotune() {
       float best = 1e30f;
       int best_cfg = -1;
       char key[256];
-      snprintf(key, sizeof key, "%s/d%d/n%d/M%d/K%d/N%d/v%d", L.name.c_str(), dtype, nn, nn * L.Ho * L.Wo, L.Kpad, L.cout,
-               conv_num_cfgs());
+      snprintf(key, sizeof key, "%s/d%d/n%d/M%d/K%d/N%d/v%d/L%d", L.name.c_str(), dtype, nn, nn * L.Ho * L.Wo, L.Kpad, L.cout,
+               conv_num_cfgs(), lanes);
       const auto hit = cache.find(key);
       if (hit != cache.end()) {
         ConvArgs a = conv_args(L, 0, nn);
@@ -169,12 +181,26 @@ int Encoder::autotune() {
         float ms = 1e30f;
         for (int trial = 0; trial < 2; ++trial) {
           const int reps = 4;
-          VNF_HIP(hipEventRecord(e0, 0));
-          for (int r = 0; r < reps; ++r) (void)launch_conv(a, 0);
-          VNF_HIP(hipEventRecord(e1, 0));
-          VNF_HIP(hipEventSynchronize(e1));
           float t = 0;
-          VNF_HIP(hipEventElapsedTime(&t, e0, e1));
+          if (lanes <= 1) {
+            VNF_HIP(hipEventRecord(e0, 0));
+            for (int r = 0; r < reps; ++r) (void)launch_conv(a, 0);
+            VNF_HIP(hipEventRecord(e1, 0));
+            VNF_HIP(hipEventSynchronize(e1));
+            VNF_HIP(hipEventElapsedTime(&t, e0, e1));
+          } else {
+            VNF_HIP(hipDeviceSynchronize());
+            VNF_HIP(hipEventRecord(e0, lane_s[0]));
+            for (int r = 0; r < reps; ++r)
+              for (int l = 0; l < lanes; ++l) (void)launch_conv(a, lane_s[l]);
+            for (int l = 0; l < lanes; ++l) VNF_HIP(hipEventRecord(lane_e[l], lane_s[l]));
+            for (int l = 0; l < lanes; ++l) {
+              float tl = 0;
+              VNF_HIP(hipEventSynchronize(lane_e[l]));
+              VNF_HIP(hipEventElapsedTime(&tl, e0, lane_e[l]));
+              if (tl > t) t = tl;
+            }
+          }
           if (t < ms) ms = t;
         }
         if (ms < best) { best = ms; best_cfg = cfg; }
@@ -191,6 +217,10 @@ int Encoder::autotune() {
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  for (int l = 0; l < 4; ++l) {
+    if (lane_e[l]) (void)hipEventDestroy(lane_e[l]);
+    if (lane_s[l]) (void)hipStreamDestroy(lane_s[l]);
+  }
   if (cache_dirty) {
     if (FILE* f = fopen(cache_path, "w")) {
       for (auto& kv : cache) fprintf(f, "%s %d\n", kv.first.c_str(), kv.second);
