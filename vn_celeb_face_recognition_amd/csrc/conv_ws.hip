@@ -31,7 +31,10 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_ws_kernel(const
   constexpr int LA = PA / LW, LB = PB / LW;        // pieces per loader wave
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int CST = BN + 4;
-  constexpr int EPASS = (BM * CST * 4 <= S * STAGE) ? 1 : WM;  // conv_epilogue's pass count
+  // epilogue staging budget handed to conv_epilogue: one pass over the whole tile only while its per-thread residual
+  // prefetch (NIT x 8 floats, 256 consumer threads) stays within 64 registers -- beside 128 accumulators more spills
+  constexpr int EPI_LDS = (BM * CST * 4 <= S * STAGE && (BM * (BN / 8)) / (NC * 64) <= 8) ? S * STAGE : (BM / WM) * CST * 4;
+  constexpr int EPASS = (BM * CST * 4 <= EPI_LDS) ? 1 : WM;  // conv_epilogue's pass count
   static_assert(S >= 3 && PA % LW == 0 && PB % LW == 0, "pieces divide over the loader waves");
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -124,26 +127,32 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_ws_kernel(const
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  uint4 xf[2][TM], wf[2][TN];
+  // Big wave tiles (8x4 MFMA tiles = 128 accumulator registers) keep ONE fragment set: two would spill.  Their 32
+  // MFMAs per half K tile (512 cycles) dwarf the exposed read latency anyway; smaller tiles double-buffer.
+  constexpr bool PIPE = (TM + TN) < 12;
+  constexpr int NF = PIPE ? 2 : 1;
+  uint4 xf[NF][TM], wf[NF][TN];
   auto read_frags = [&](int kt, int ks) {
+    const int fs = PIPE ? ks : 0;
     const char* sA = smem + (kt % S) * STAGE;
     const char* sB = sA + BM * 128;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = wm * WTM + i * 16 + frow;
-      xf[ks][i] = *reinterpret_cast<const uint4*>(sA + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+      xf[fs][i] = *reinterpret_cast<const uint4*>(sA + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int row = wn * WTN + j * 16 + frow;
-      wf[ks][j] = *reinterpret_cast<const uint4*>(sB + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+      wf[fs][j] = *reinterpret_cast<const uint4*>(sB + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
     }
   };
   auto mma = [&](int ks) {
+    const int fs = PIPE ? ks : 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], wf[ks][j], xf[ks][i]);
+      for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], wf[fs][j], xf[fs][i]);
   };
   bool pend = false;
   for (int kt = 0; kt < nkt; ++kt) {
@@ -164,15 +173,24 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_ws_kernel(const
       continue;
     }
     wait_dma_and_barrier<0>();  // no DMA of its own: drains this wave's fragment reads, then joins
-    read_frags(kt, 0);
-    if (pend) mma(1);
-    pend = BKE / 2 < a.K - kt * BKE;
-    if (pend) read_frags(kt, 1);
-    mma(0);
+    if constexpr (PIPE) {
+      read_frags(kt, 0);
+      if (pend) mma(1);
+      pend = BKE / 2 < a.K - kt * BKE;
+      if (pend) read_frags(kt, 1);
+      mma(0);
+    } else {
+      read_frags(kt, 0);
+      mma(0);
+      if (BKE / 2 < a.K - kt * BKE) {
+        read_frags(kt, 1);
+        mma(1);
+      }
+    }
   }
   if (pend) mma(1);
   __syncthreads();
-  conv_epilogue<T, BM, BN, WM, WN, S * STAGE>(a, acc, smem, m0, n0);
+  conv_epilogue<T, BM, BN, WM, WN, EPI_LDS>(a, acc, smem, m0, n0);
 }
 
 // ===================================================================== host side
