@@ -110,7 +110,7 @@ def run_pipeline(args):
     # other's host synchronisations (FacePipeline.submit)
     det = [models.MTCNN(keep_all=True, min_face_size=50, device=dev, max_batch=NF, max_height=1080, max_width=1920)
            for _ in range(args.detectors)]
-    enc = models.InceptionResnetV1(pretrained=None, compute_dtype=args.dtype, max_batch=256).to(dev).eval()
+    enc = models.InceptionResnetV1(pretrained=None, compute_dtype=args.dtype, max_batch=max(256, args.embed_batch)).to(dev).eval()
     clf = models.MLPModel(512, 1001).to(dev).eval()
     pipe = FacePipeline(det, enc, clf, {"label": list(range(1001)), "name": ["c%d" % i for i in range(1001)]}, 160, 0.0,
                         embed_batch=args.embed_batch, embed_lanes=args.lanes)

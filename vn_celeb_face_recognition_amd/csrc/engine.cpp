@@ -828,6 +828,16 @@ int build_onet(Encoder& e, WeightMap& wm) {
 // concurrently on side streams (fork / join with events on the caller's stream): the small late
 // layers (a few hundred workgroups, latency-bound) of one part fill the CUs the other leaves idle,
 // and kernel-boundary drains overlap.
+Encoder::~Encoder() {
+  for (int i = 0; i < 4; ++i) {
+    if (join_ev[i]) (void)hipEventDestroy(join_ev[i]);
+    if (side[i]) (void)hipStreamDestroy(side[i]);
+  }
+  if (fork_ev) (void)hipEventDestroy(fork_ev);
+  for (hipEvent_t ev : ctx_ev)
+    if (ev) (void)hipEventDestroy(ev);
+}
+
 int Encoder::select_ctx(hipStream_t s, int* used) {
   const int es = dtype_size(dtype);
   if (ctx_bufs.empty()) {  // context 0 = the buffers finalize() allocated

@@ -78,6 +78,7 @@ struct Group { int first, last, chunk; };  // ops [first,last) run per `chunk` i
 struct Tap { int buf, coff, C; };
 
 struct Encoder : HandleBase {
+  ~Encoder() override;  // side streams, fork/join and context events (device buffers: HandleBase)
   int arch, dtype, max_batch, in_size;
   std::vector<Buf> bufs;
   std::vector<ConvLayer> convs;
