@@ -61,11 +61,16 @@ def cal_embedding(data_dir, batch_size, model, transforms, output_dir, device, r
     list_files = sorted(os.listdir(data_dir))
     lo, hi = vdist.shard_range(len(list_files), rank, world)     # files are independent units
     list_batch_files, n_batchs = create_batch_images(list_files[lo:hi], batch_size)
-    for idx, batch_file in enumerate(list_batch_files):
-        print('Processing for {}/{} batchs:'.format(idx, n_batchs))
-        tensors = create_image_tensors(Path(data_dir), batch_file, transforms).to(device)
-        embeddings = model(tensors).detach().cpu().numpy()
-        save_embeddings(embeddings, batch_file, output_dir)
+    def batches():
+        for idx, batch_file in enumerate(list_batch_files):
+            print('Processing for {}/{} batchs:'.format(idx, n_batchs))
+            yield create_image_tensors(Path(data_dir), batch_file, transforms)
+
+    # batches are independent: up to three are in flight on rotating streams (the next batch's decode and upload
+    # and the previous batch's .npz writes overlap the GPU work)
+    for idx, emb, ready in model.embed_stream(batches(), lanes=3):
+        ready.synchronize()
+        save_embeddings(emb.detach().cpu().numpy(), list_batch_files[idx], output_dir)
 
 
 if __name__ == "__main__":

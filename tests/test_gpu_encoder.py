@@ -158,3 +158,9 @@ def test_activation_contexts_let_calls_on_different_streams_overlap_without_chan
         assert np.array_equal(o.cpu().numpy(), want[i])
     m.set_contexts(1)
     assert np.array_equal(m(xs[0]).cpu().numpy(), want[0])
+    # the same through the host-side helper (host tensors in, rotating lanes inside)
+    got = {}
+    for i, emb, ready in m.embed_stream([x.cpu() for x in xs] * 2, lanes=3):
+        ready.synchronize()
+        got[i] = emb.cpu().numpy()
+    assert sorted(got) == list(range(6)) and all(np.array_equal(got[i], want[i % 3]) for i in got)

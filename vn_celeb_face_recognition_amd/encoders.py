@@ -153,6 +153,34 @@ class _Encoder:
         on different streams overlap on the GPU."""
         _lib.check(_lib.load().vnf_encoder_set_contexts(self._ensure_handle(), int(n)))
 
+    def embed_stream(self, batches, lanes=3):
+        """Throughput mode over an iterable of independent (N,3,S,S) batches (host or cuda tensors): batch i runs on
+        stream i % lanes over the encoder's activation contexts, so up to `lanes` batches are in flight on the GPU;
+        yields (index, embeddings (N,512) cuda, ready_event) in order -- wait on / synchronise the event before
+        reading.  What find_embedding.py's loop over a directory becomes (find_embedding.py:44-59)."""
+        dev = self.device if isinstance(self.device, torch.device) else torch.device(self.device)
+        lanes = max(1, min(4, int(lanes)))
+        if lanes > 1:
+            self.set_streams(1)
+            self.set_contexts(lanes)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        start = torch.cuda.current_stream(dev).record_event()
+        for s_ in streams:
+            s_.wait_event(start)
+        inflight = []
+        for i, x in enumerate(batches):
+            s_ = streams[i % lanes]
+            with torch.cuda.stream(s_):
+                x = x.to(dev, non_blocking=True)
+                emb = self(x)
+                ev = s_.record_event()
+            x.record_stream(s_)
+            inflight.append((i, emb, ev))
+            if len(inflight) >= lanes:
+                yield inflight.pop(0)
+        for item in inflight:
+            yield item
+
     # ---- extras used by tests / bench
     def tap(self, name, n):
         """Copy an internal activation of the last forward (first n images) to a (n,C,H,W) fp32 array."""
