@@ -192,8 +192,8 @@ def main():
                          "embed workload's encoder then splits each batch over two internal streams instead); default 3 for the "
                          "embed workload, 1 for the pipeline (measured best)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--model", default="irv1", choices=["irv1", "ir100"],
                     help="irv1 = BASELINE configs[1] (default); ir100 = configs[4], the ArcFace IR-100 swap-in")

@@ -137,7 +137,7 @@ int vnf_encoder_set_streams(vnf_handle h, int max_streams) {
   if (max_streams < 1 || max_streams > 4) return fail(VNF_E_INVALID, "vnf_encoder_set_streams: 1..4");
   if (e->max_streams != max_streams) {
     e->max_streams = max_streams;
-    return e->autotune();  // the part size the layers see changed: pick the tiles again
+    e->tune_dirty = true;  // the part size the layers see changed: the next vnf_embed picks the tiles again
   }
   return VNF_OK;
   API_GUARD_END
@@ -152,7 +152,7 @@ int vnf_encoder_set_contexts(vnf_handle h, int n) {
   e->next_ctx = 0;
   if (e->tune_lanes != n) {
     e->tune_lanes = n;
-    return e->autotune();  // pick the tiles for `n` kernels sharing the GPU
+    e->tune_dirty = true;  // the next vnf_embed picks the tiles for `n` kernels sharing the GPU
   }
   return VNF_OK;
   API_GUARD_END

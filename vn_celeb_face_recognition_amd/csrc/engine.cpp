@@ -141,6 +141,9 @@ int Encoder::autotune() {
       fclose(f);
     }
   }
+  // tuning launches scribble over the activation buffers: nothing of an earlier vnf_embed may still be in flight,
+  // and nothing of the tuner when the caller's launches start
+  VNF_HIP(hipDeviceSynchronize());
   hipEvent_t e0, e1;
   VNF_HIP(hipEventCreate(&e0));
   VNF_HIP(hipEventCreate(&e1));
@@ -221,6 +224,7 @@ int Encoder::autotune() {
     if (lane_e[l]) (void)hipEventDestroy(lane_e[l]);
     if (lane_s[l]) (void)hipStreamDestroy(lane_s[l]);
   }
+  VNF_HIP(hipDeviceSynchronize());
   if (cache_dirty) {
     if (FILE* f = fopen(cache_path, "w")) {
       for (auto& kv : cache) fprintf(f, "%s %d\n", kv.first.c_str(), kv.second);
@@ -243,7 +247,8 @@ int Encoder::finalize() {
   macs_alg = macs_exec = 0;
   for (auto& c : convs) { macs_alg += c.macs_alg; macs_exec += c.macs_exec; }
   if (groups.empty()) groups.push_back({0, (int)ops.size(), 1 << 30});
-  return autotune();
+  tune_dirty = true;  // the first run() picks the tiles (after any set_streams / set_contexts of the caller)
+  return VNF_OK;
 }
 
 struct Piece {  // output channels contributed by one reference conv / linear
@@ -873,6 +878,11 @@ int Encoder::select_ctx(hipStream_t s, int* used) {
 int Encoder::run(const void* x, int n, int x_dtype, float* out, hipStream_t s, std::string* report) {
   if (n < 0 || n > max_batch) return fail(VNF_E_CAPACITY, "batch exceeds max_batch");
   if (n == 0) return VNF_OK;
+  if (tune_dirty) {
+    tune_dirty = false;
+    const int rc = autotune();
+    if (rc != VNF_OK) return rc;
+  }
   if (n_ctx > 1) {
     int c = 0;
     int rc = select_ctx(s, &c);

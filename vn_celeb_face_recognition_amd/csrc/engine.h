@@ -104,6 +104,7 @@ struct Encoder : HandleBase {
   std::vector<hipEvent_t> ctx_ev;
   int select_ctx(hipStream_t s, int* used);
   int max_streams = 4;  // cap on run()'s batch split (1: never fork side streams)
+  bool tune_dirty = true;  // tiles are (re)picked lazily at the next run(): create, set_streams and set_contexts only mark
   int tune_lanes = 1;   // concurrent copies the autotuner times each candidate as (set with the context count)
   int tune_batch = 0;   // batch size the autotuner times at (0: the part size run() uses at max_batch)
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
