@@ -20,7 +20,7 @@ from demo_image import build_models, build_parser
 from vn_celeb_face_recognition_amd import dist as vdist
 from vn_celeb_face_recognition_amd.cli_utils import (append_log_to_file, convert_sec_to_max_time_quantity,
                                                      draw_boxes_on_image, open_frame_source, write_rgb)
-from vn_celeb_face_recognition_amd.pipeline import FacePipeline
+from vn_celeb_face_recognition_amd.pipeline import FacePipeline, identify_names
 
 
 def tracker_row(time_in_video, frame_idx, names, bboxes, frame_shape):
@@ -61,8 +61,25 @@ def main(args, pipe, rank, world):
             if batch_id % world == 0:
                 end_round()
 
+    inflight = []  # single rank: tickets of the throughput pipeline, retired in order
+
+    def retire(item):
+        t, q, inf = item
+        counts, boxes, emb, amax, prob = t.result()
+        names = identify_names(amax, prob, pipe.classifier.num_classes, pipe.label2name, pipe.threshold) if len(boxes) else []
+        o = 0
+        for idx, c in enumerate(counts):
+            nm, bx = names[o:o + c], [boxes[k] for k in range(o, o + c)]
+            o += c
+            if args.save_frame_recognized:
+                img = draw_boxes_on_image(q[idx], bx, nm) if nm else q[idx]
+                write_rgb(os.path.join(args.output_frame, 'frame_{}.png'.format(inf[idx][1])), img)
+            rows[inf[idx][1]] = tracker_row(inf[idx][0], inf[idx][1], nm, bx, q[idx].shape)
+
     def end_round():
-        """Every rank runs its batch (or none), then ALL ranks meet in the embedding all-gather."""
+        """Every rank runs its batch (or none), then ALL ranks meet in the embedding all-gather.  A single rank has
+        nobody to meet: its batches go through FacePipeline.submit (detection and embedding streams overlap, faces of
+        consecutive batches embedded together) and are retired two batches later."""
         nonlocal processed_frame
         emb = torch.empty((0, 512), dtype=torch.float32, device='cuda')
         if pending:
@@ -70,6 +87,12 @@ def main(args, pipe, rank, world):
             processed_frame += len(q)
             if (processed_frame % args.log_step) == 0:
                 print('Processing for frame: {}, time: {}'.format(inf[-1][1], convert_sec_to_max_time_quantity(inf[-1][0])))
+            if world == 1:
+                frames_dev, _ = pipe.detector._to_device_frames(q)
+                inflight.append((pipe.submit(frames_dev), q, inf))
+                while len(inflight) > 2:
+                    retire(inflight.pop(0))
+                return
             bth_names, bth_boxes, emb = pipe.recognize_frames(q)
             for idx, names in enumerate(bth_names):
                 if args.save_frame_recognized:
@@ -89,6 +112,9 @@ def main(args, pipe, rank, world):
     take(queue, info)
     if batch_id % world != 0:
         end_round()
+    pipe.flush()
+    while inflight:
+        retire(inflight.pop(0))
     if world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, rows)
@@ -124,7 +150,8 @@ if __name__ == '__main__':
     device = 'cuda:%d' % local
     torch.cuda.set_device(local)
     label2name_df, detection_md, emb_model, classify_model = build_models(args, device)
-    pipe = FacePipeline(detection_md, emb_model, classify_model, label2name_df, args.target_face_size, args.recog_threshold)
+    pipe = FacePipeline(detection_md, emb_model, classify_model, label2name_df, args.target_face_size, args.recog_threshold,
+                        embed_batch=256 if world == 1 else 0)
     main(args, pipe, rank, world)
     if world > 1:
         dist.destroy_process_group()
