@@ -411,7 +411,7 @@ int build_irv1(Encoder& e, WeightMap& wm) {
   (void)ch;
   const int b_in = e.add_buf(160, 160, 8);
   const int b_1a = e.add_buf(79, 79, 32), b_2a = e.add_buf(77, 77, 32), b_2b = e.add_buf(77, 77, 64);
-  const int b_3a = e.add_buf(38, 38, 64), b_3b = e.add_buf(38, 38, 96), b_4a = e.add_buf(36, 36, 192);
+  const int b_3a = e.add_buf(38, 38, 64), b_3b = e.add_buf(38, 38, 80), b_4a = e.add_buf(36, 36, 192);
   const int x35[3] = {e.add_buf(17, 17, 256), e.add_buf(17, 17, 256), e.add_buf(17, 17, 256)};
   const int t35a = e.add_buf(17, 17, 64), t35b = e.add_buf(17, 17, 32), cat35 = e.add_buf(17, 17, 96);
   const int m6a = e.add_buf(17, 17, 192), m6b = e.add_buf(17, 17, 192);
@@ -491,8 +491,8 @@ int build_irv1(Encoder& e, WeightMap& wm) {
   TRY(simple("conv2d_2a", b_1a, 0, 32, 32, 32, 3, 3, 1, 0, 0, b_2a, 0));
   TRY(simple("conv2d_2b", b_2a, 0, 32, 32, 64, 3, 3, 1, 1, 1, b_2b, 0));
   add_maxpool(e, b_2b, b_3a, 0);
-  TRY(simple("conv2d_3b", b_3a, 0, 64, 64, 80, 1, 1, 1, 0, 0, b_3b, 0, 96));
-  TRY(simple("conv2d_4a", b_3b, 0, 80, 96, 192, 3, 3, 1, 0, 0, b_4a, 0));
+  TRY(simple("conv2d_3b", b_3a, 0, 64, 64, 80, 1, 1, 1, 0, 0, b_3b, 0));
+  TRY(simple("conv2d_4a", b_3b, 0, 80, 80, 192, 3, 3, 1, 0, 0, b_4a, 0));
   TRY(simple("conv2d_4b", b_4a, 0, 192, 192, 256, 3, 3, 2, 0, 0, x35[0], 0));
   const int stem_end = (int)e.ops.size();
   e.taps["conv2d_1a"] = {b_1a, 0, 32}; e.taps["conv2d_2a"] = {b_2a, 0, 32}; e.taps["conv2d_2b"] = {b_2b, 0, 64};
