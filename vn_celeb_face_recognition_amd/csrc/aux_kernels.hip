@@ -126,31 +126,32 @@ __global__ void maxpool3s2_kernel(const T* __restrict__ x, int ldx, T* __restric
                                   int C) {
   constexpr int CH = 16 / (int)sizeof(T);
   const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1, cc = C / CH;
-  const size_t total = (size_t)n * Ho * Wo * cc;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cc) * CH;
-    const size_t p = i / cc;
-    const int wo = (int)(p % Wo);
-    const size_t q = p / Wo;
-    const int ho = (int)(q % Ho);
-    const size_t img = q / Ho;
+  const unsigned total = (unsigned)n * Ho * Wo * cc;  // < 2^31, checked by the launcher: 32-bit index math
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned p = i / cc;
+    const int c = (int)(i - p * cc) * CH;
+    const unsigned q = p / Wo;
+    const int wo = (int)(p - q * Wo);
+    const unsigned img = q / Ho;
+    const int ho = (int)(q - img * Ho);
     float m[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) m[e] = -3.4e38f;
+    const T* xi = x + ((size_t)img * H * W + (size_t)(2 * ho) * W + 2 * wo) * ldx + c;
+    T v[9][CH];
 #pragma unroll
     for (int dh = 0; dh < 3; ++dh)
 #pragma unroll
-      for (int dw = 0; dw < 3; ++dw) {
-        const T* src = x + ((img * H + (2 * ho + dh)) * W + (2 * wo + dw)) * (size_t)ldx + c;
-        T v[CH];
-        *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(src);
+      for (int dw = 0; dw < 3; ++dw)   // nine independent 16-byte loads in flight
+        *reinterpret_cast<uint4*>(v[dh * 3 + dw]) = *reinterpret_cast<const uint4*>(xi + (size_t)(dh * W + dw) * ldx);
 #pragma unroll
-        for (int e = 0; e < CH; ++e) m[e] = fmaxf(m[e], (float)v[e]);
-      }
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < CH; ++e) m[e] = fmaxf(m[e], (float)v[t][e]);
     T o[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) o[e] = (T)m[e];
-    *reinterpret_cast<uint4*>(y + p * (size_t)ldy + c) = *reinterpret_cast<const uint4*>(o);
+    *reinterpret_cast<uint4*>(y + (size_t)p * ldy + c) = *reinterpret_cast<const uint4*>(o);
   }
 }
 
@@ -161,7 +162,8 @@ hipError_t launch_maxpool3s2(const void* x, int ldx, void* y, int ldy, int dtype
   if (C % ch) return hipErrorInvalidValue;
   const size_t total = (size_t)n * Ho * Wo * (C / ch);
   if (total == 0) return hipSuccess;
-  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (total >= (1u << 31)) return hipErrorInvalidValue;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   switch (dtype) {
     case BF16: hipLaunchKernelGGL(maxpool3s2_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)x, ldx, (__bf16*)y, ldy, n, H, W, C); break;
     case F16: hipLaunchKernelGGL(maxpool3s2_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)x, ldx, (_Float16*)y, ldy, n, H, W, C); break;
