@@ -305,8 +305,9 @@ def main():
                        "lanes": len(lanes)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "traffic_note": "HBM bytes per step, FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE from separate "
-                                         "rocprofv3 --pmc passes (profiles/r01_traffic.json); algorithmic floor 87 MB",
+                         "traffic_note": "memory-side bytes per step, FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE from separate "
+                                         "rocprofv3 --pmc passes (profiles/r01_traffic.json); these L2 fabric counters include "
+                                         "Infinity-Cache hits, so HBM proper is at most this; algorithmic floor 87 MB",
                          "kernel": "implicit-GEMM convolution kernels conv_igemm_dma / conv_patch / conv_igemm_ws (every launch of one "
                                    "embed step, tile configuration per layer chosen by the create-time autotuner; device time by HIP events)",
                          "flop_per_step_algorithmic": flop_per_step,
