@@ -183,6 +183,8 @@ static const PatchCfg kPatch[] = {
     {128, 64, 2, 2, 3},  {64, 64, 2, 2, 4},   {256, 192, 4, 2, 3}, {128, 192, 2, 4, 3}, {64, 192, 2, 4, 3},
     {128, 256, 2, 4, 3}, {256, 256, 4, 2, 3}, {128, 128, 2, 4, 3}, {256, 128, 4, 2, 3}, {64, 128, 2, 4, 3},
     {64, 128, 2, 2, 4},
+    // deeper weight rings: the patch is resident, so ring stages are only BN x 128 B and more of them keep more bytes in flight
+    {256, 64, 4, 2, 6},  {128, 64, 4, 2, 6},  {256, 128, 4, 2, 4}, {256, 32, 8, 1, 6},
 };
 constexpr int kNumPatch = (int)(sizeof(kPatch) / sizeof(kPatch[0]));
 
@@ -276,6 +278,10 @@ static hipError_t launch_patch_typed(int pcfg, const KArgs& k, int lds, hipStrea
     case 13: return launch_one<T, 256, 128, 4, 2, 3>(k, lds, s);
     case 14: return launch_one<T, 64, 128, 2, 4, 3>(k, lds, s);
     case 15: return launch_one<T, 64, 128, 2, 2, 4>(k, lds, s);
+    case 16: return launch_one<T, 256, 64, 4, 2, 6>(k, lds, s);
+    case 17: return launch_one<T, 128, 64, 4, 2, 6>(k, lds, s);
+    case 18: return launch_one<T, 256, 128, 4, 2, 4>(k, lds, s);
+    case 19: return launch_one<T, 256, 32, 8, 1, 6>(k, lds, s);
   }
   return hipErrorInvalidValue;
 }
