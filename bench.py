@@ -91,6 +91,70 @@ def cpu_baseline_pipeline(frames, template_size=160, n_frames=32, budget_s=12.0)
             "sample": "%d of the synthetic 1080p frames (%d faces), oracle detect+align+embed+classify, %.1f s" % (n_frames, faces, dt)}
 
 
+def run_detect(args):
+    """--workload detect: SURVEY.md 8(d) config 3 -- MTCNN detect + 5-point alignment only, synthetic 1080p frames,
+    16 frames per step, frames resident in HBM; roofline = HBM on the stage-1 algorithmic bytes (a lower bound for
+    the whole cascade).  Two detector handles on two host threads keep the GPU busy across each other's three host
+    synchronisations."""
+    import threading
+    import torch
+    from vn_celeb_face_recognition_amd import models
+    from vn_celeb_face_recognition_amd.pipeline import align_faces_device, center_point_dict
+    from vn_celeb_face_recognition_amd.synth import make_frames
+    if args.gpus != 1:
+        raise SystemExit("--workload detect is a single-GPU line (frames shard like the pipeline workload)")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    NF, PER, NT = 16, 8, max(1, args.detectors)
+    frames, _ = make_frames(NF * 2, PER, seed=0)
+    batches = [torch.from_numpy(frames[i * NF:(i + 1) * NF]).to(dev) for i in range(2)]
+    dets = [models.MTCNN(keep_all=True, min_face_size=50, device=dev, max_batch=NF, max_height=1080, max_width=1920)
+            for _ in range(NT)]
+    tmpl = center_point_dict["(160, 160)"]
+    faces = [0] * NT
+
+    def work(k, first, n):
+        torch.cuda.set_device(dev)
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            for i in range(first, first + n):
+                counts, boxes, probs, points = dets[k].detect_device(batches[i & 1])
+                nb = len(boxes)
+                if nb:
+                    fidx, bx, _, pt = dets[k].results_device(nb, dev)
+                    align_faces_device(batches[i & 1], fidx, bx, pt, tmpl, 160, want_u8=False, norm_dtype=torch.bfloat16)
+                faces[k] += nb
+        st.synchronize()
+
+    def run(total):
+        per = [total // NT + (1 if k < total % NT else 0) for k in range(NT)]
+        ths = [threading.Thread(target=work, args=(k, sum(per[:k]), per[k])) for k in range(NT)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    faces[:] = [0] * NT
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    stage1_bytes = 13_316_400.0 * NF
+    achieved = stage1_bytes * args.steps / wall / 1e9
+    print(json.dumps({
+        "metric": "frames/sec MTCNN detect+align on 1080p frames (SURVEY 8d config 3)", "value": round(NF * args.steps / wall, 1),
+        "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "MTCNN P/R/O cascade + 5-point warp, synthetic 1080p frames, %d frames/step, %d pasted "
+                               "faces/frame, min_face_size 50, %d detector handle(s)/thread(s)" % (NF, PER, NT),
+                   "faces_per_s": round(sum(faces) / wall, 1)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(achieved / 8000.0, 5), "traffic": None,
+                     "kernel": "whole cascade priced on stage-1 (pyramid + P-Net) algorithmic bytes only: a lower bound"}}), flush=True)
+
+
 def run_pipeline(args):
     """--workload pipeline: BASELINE.json configs[2]/[3] -- faces/sec end to end (detect + align + embed +
     classify) on synthetic 1080p frames, 16 frames per step per GPU, frames resident in HBM."""
@@ -182,7 +246,7 @@ def run_pipeline(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="embed", choices=["embed", "pipeline"])
+    ap.add_argument("--workload", default="embed", choices=["embed", "pipeline", "detect"])
     ap.add_argument("--embed-batch", type=int, default=256,
                     help="pipeline workload: faces of consecutive frame batches are embedded together once this many wait "
                          "(0: every frame batch on its own)")
@@ -203,6 +267,8 @@ def main():
         args.lanes = 3 if args.workload == "embed" else 1
     if args.workload == "pipeline":
         return run_pipeline(args)
+    if args.workload == "detect":
+        return run_detect(args)
 
     import torch
     import torch.distributed as dist

@@ -20,6 +20,7 @@ cp $OUT/${R}_traffic.json $ROOT/profiles/${R}_traffic.json   # bench.py quotes i
 # 2. the bench lines
 python bench.py > $OUT/${R}_bench_embed.json 2> $OUT/bench_embed.err || exit 1
 python bench.py --workload pipeline > $OUT/${R}_bench_pipeline.json 2> $OUT/bench_pipeline.err || exit 1
+python bench.py --workload detect --detectors 2 > $OUT/${R}_bench_detect.json 2>/dev/null || exit 1
 python bench.py --dtype f32 --no-cpu-baseline > $OUT/${R}_bench_embed_f32.json 2>/dev/null || exit 1
 python bench.py --model ir100 --no-cpu-baseline > $OUT/${R}_bench_ir100.json 2>/dev/null || exit 1
 python tools/profile_encoder.py 256 bf16 > $OUT/${R}_irv1_bs256_bf16_layer_times.txt 2>/dev/null || exit 1
