@@ -11,6 +11,14 @@ random-init generator weights (seed 0; no pretrained weights exist offline).  Wi
 rank embeds its own 256 crops (weak scaling, no data-path collective) and the ranks exchange the
 resulting (256,512) fp32 embeddings with one RCCL all-gather per step, overlapped with the next
 step.  Rank 0 prints ONE JSON line.
+
+The default run (no --workload) carries, inside that one line:
+  * the headline leg (value / ms_per_step / roofline / cpu_baseline): bf16, BASELINE configs[1];
+  * "parity": measured L2 error of the timed dtype against the reference's own embeddings (tests/golden/
+    irv1_seed0.npz) next to the 1e-4 north-star gate, and whether the timed 3-lane bs=256 output equals the same
+    images embedded 8 at a time on one stream (bitwise) -- so the line says which path is inside the gate;
+  * "legs": the same workload timed in the other compute dtypes (f16x2 = split-f16, inside the gate; f16; f32);
+  * "pipeline": BASELINE's other half -- faces/sec end to end on synthetic 1080p frames (16 frames/step/GPU).
 """
 import argparse
 import json
@@ -155,18 +163,14 @@ def run_detect(args):
                      "kernel": "whole cascade priced on stage-1 (pyramid + P-Net) algorithmic bytes only: a lower bound"}}), flush=True)
 
 
-def run_pipeline(args):
-    """--workload pipeline: BASELINE.json configs[2]/[3] -- faces/sec end to end (detect + align + embed +
-    classify) on synthetic 1080p frames, 16 frames per step per GPU, frames resident in HBM."""
+def pipeline_leg(args, rank, world, local, steps, warmup, lanes, want_cpu):
+    """BASELINE.json configs[2]/[3] -- faces/sec end to end (detect + align + embed + classify) on synthetic 1080p
+    frames, 16 frames per step per GPU, frames resident in HBM.  Returns the result dict on rank 0 (None elsewhere)."""
     import torch
     import torch.distributed as dist
     from vn_celeb_face_recognition_amd import dist as vdist, models
     from vn_celeb_face_recognition_amd.pipeline import FacePipeline
     from vn_celeb_face_recognition_amd.synth import make_frames
-    rank, world, local = vdist.init_from_env("nccl")
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     NF, PER = 16, 8
     frames, truth = make_frames(NF * 2, PER, seed=rank)
@@ -177,7 +181,7 @@ def run_pipeline(args):
     enc = models.InceptionResnetV1(pretrained=None, compute_dtype=args.dtype, max_batch=max(256, args.embed_batch)).to(dev).eval()
     clf = models.MLPModel(512, 1001).to(dev).eval()
     pipe = FacePipeline(det, enc, clf, {"label": list(range(1001)), "name": ["c%d" % i for i in range(1001)]}, 160, 0.0,
-                        embed_batch=args.embed_batch, embed_lanes=args.lanes)
+                        embed_batch=args.embed_batch, embed_lanes=lanes)
     batches = [torch.from_numpy(frames[i * NF:(i + 1) * NF]).to(dev) for i in range(2)]
 
     inflight = []
@@ -202,7 +206,7 @@ def run_pipeline(args):
             n += retire(inflight.pop(0))
         return n
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     drain()
     if world > 1:
@@ -210,7 +214,7 @@ def run_pipeline(args):
     torch.cuda.synchronize()
     faces = 0
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         faces += step(i)
     faces += drain()
     if world > 1:
@@ -222,82 +226,79 @@ def run_pipeline(args):
     if world > 1:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); wall = float(mx[0])
         dist.all_reduce(tot); faces = int(tot[1].item())
+    stage_ms = det[0].stage_times(batches[0]) if rank == 0 else None
+    out = None
     if rank == 0:
-        stage1_bytes = 13_316_400.0 * NF      # stage-1 algorithmic bytes per 1080p frame, min_face 50
-        achieved = stage1_bytes * args.steps / wall / 1e9
         out = {"metric": "faces/sec end-to-end (detect+embed+classify) on 1080p frames", "value": round(faces / wall, 1),
-               "unit": "faces/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+               "unit": "faces/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+               "ms_per_step": round(wall * 1e3 / steps, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[2]+[3]: MTCNN detect + align + IRv1 embed + MLP classify, "
                                       "synthetic 1080p frames, %d frames/step/GPU, %d pasted faces/frame; detection and embedding on "
                                       "separate streams, faces embedded in groups of >= %d" % (NF, PER, args.embed_batch),
-                          "frames_per_s": round(world * NF * args.steps / wall, 1), "min_face_size": 50},
-               "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                            "frac": round(achieved / 8000.0, 5), "traffic": None,
-                            "kernel": "whole step priced on stage-1 (pyramid + P-Net) algorithmic bytes only: a lower bound"}}
-        if not args.no_cpu_baseline and world == 1:
+                          "frames_per_s": round(world * NF * steps / wall, 1), "min_face_size": 50},
+               "roofline": pipeline_roofline(stage_ms, NF)}
+        if want_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline_pipeline(frames)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    del pipe, det, enc, clf
+    torch.cuda.empty_cache()
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="embed", choices=["embed", "pipeline", "detect"])
-    ap.add_argument("--embed-batch", type=int, default=256,
-                    help="pipeline workload: faces of consecutive frame batches are embedded together once this many wait "
-                         "(0: every frame batch on its own)")
-    ap.add_argument("--detectors", type=int, default=1, help="pipeline workload: detector handles (host threads) per GPU")
-    ap.add_argument("--lanes", type=int, default=0,
-                    help="streams / encoder activation contexts that consecutive embed launches rotate over (1: one stream; the "
-                         "embed workload's encoder then splits each batch over two internal streams instead); default 3 for the "
-                         "embed workload, 1 for the pipeline (measured best)")
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--model", default="irv1", choices=["irv1", "ir100"],
-                    help="irv1 = BASELINE configs[1] (default); ir100 = configs[4], the ArcFace IR-100 swap-in")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-    if args.lanes <= 0:
-        args.lanes = 3 if args.workload == "embed" else 1
-    if args.workload == "pipeline":
-        return run_pipeline(args)
-    if args.workload == "detect":
-        return run_detect(args)
+def pipeline_roofline(stages, nf):
+    """HBM roofline of the detection front end, per kernel: algorithmic bytes of one launch (SURVEY.md 8d terms from the
+    level table x the frames one launch processes, computed by the library) / that kernel's device time, measured live
+    with HIP events on the detector's stream (vnf_mtcnn_stage_times).  The headline entry is the pyramid kernel: it
+    is the one that reads every frame byte (6 220 800 B u8 + 2 890 236 B of fp32 levels written, per 1080p frame)."""
+    if not stages:
+        return {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None}
+    per = {}
+    for name, v in stages.items():
+        if v["bytes"] > 0 and v["ms"] > 0:
+            gbps = v["bytes"] / v["ms"] / 1e6
+            per[name] = {"bytes_per_launch": v["bytes"], "ms": round(v["ms"], 4), "GBps": round(gbps, 1), "frac": round(gbps / 8000.0, 4)}
+    dom = per.get("pyramid", {})
+    return {"bound": "hbm", "achieved": dom.get("GBps"), "peak": 8000.0, "unit": "GB/s", "frac": dom.get("frac"), "traffic": None,
+            "kernel": "pyramid_rows_kernel (all pyramid levels of the %d frames in one launch): (frame u8 bytes + fp32 level bytes) x %d "
+                      "frames per launch / its HIP-event time on the detector stream" % (nf, nf),
+            "per_kernel": per, "stage_ms": {k: round(v["ms"], 4) for k, v in stages.items()}}
 
+
+ROUND = "r02"   # profiles/<ROUND>_traffic.json is quoted in roofline.traffic
+# float64 sum of |embedding| over the bs=256 seed-0 bf16 input of the headline leg; tests/test_gpu_bench_config.py
+# asserts the same value on the same configuration (deterministic kernels: any change of the arithmetic shows here)
+CHECKSUMS = {}
+
+
+def embed_leg(args, dtype, rank, world, dev, n_lanes, steps, warmup, want_cpu, with_parity=True):
+    """Time the embed path in one compute dtype: `warmup` untimed + exactly `steps` timed steps bracketed by barrier +
+    synchronize; consecutive (independent) batches rotate over `n_lanes` streams / activation contexts.  Returns the
+    result dict (rank 0) or None."""
+    import numpy as np
     import torch
     import torch.distributed as dist
     from vn_celeb_face_recognition_amd import dist as vdist
     from vn_celeb_face_recognition_amd.models import InceptionResnetV1, iresnet100
     from vn_celeb_face_recognition_amd.weights import IR100_MACS_PER_IMAGE, IRV1_MACS_PER_IMAGE
 
-    rank, world, local = vdist.init_from_env("nccl")
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    # input tensor dtype: the 16-bit storage paths take 16-bit crops (BASELINE configs[1]: "synthetic 160x160 bf16"),
+    # the fp32-class paths (f32, f16x2) take fp32 crops
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f16x2": torch.float32}[dtype]
     if args.model == "irv1":
-        model = InceptionResnetV1(pretrained=None, device=dev, compute_dtype=args.dtype, max_batch=BATCH).eval()
+        model = InceptionResnetV1(pretrained=None, device=dev, compute_dtype=dtype, max_batch=BATCH).eval()
         size, macs, mname = 160, IRV1_MACS_PER_IMAGE, "InceptionResnetV1"
     else:
-        model = iresnet100(pretrained=False, compute_dtype=args.dtype, max_batch=BATCH).to(dev).eval()
+        model = iresnet100(pretrained=False, compute_dtype=dtype, max_batch=BATCH).to(dev).eval()
         size, macs, mname = 112, IR100_MACS_PER_IMAGE, "IResNet-100"
     g = torch.Generator().manual_seed(rank)
     x = torch.randn((BATCH, 3, size, size), generator=g).to(dev).to(tdt)
     gathered = [torch.empty((world * BATCH, 512), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
 
-    # Throughput mode: consecutive batches are independent, so step i runs on stream i % 2 over the encoder's two
+    # Throughput mode: consecutive batches are independent, so step i runs on stream i % lanes over the encoder's
     # activation-buffer contexts (vnf_encoder_set_contexts) with whole-batch launches (no internal half-batch forks):
     # the latency-bound tail of one batch overlaps the throughput-bound stem of the next.  Every step's work is
     # complete when the timed region's closing synchronize returns.
-    lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.lanes))]
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, n_lanes))]
     if len(lanes) > 1:
         model.set_streams(1)
         model.set_contexts(len(lanes))
@@ -311,13 +312,8 @@ def main():
                 pending = vdist.all_gather_fixed(gathered[i & 1], emb, async_op=True)
         return emb, pending
 
-    def join_lanes():
-        cur = torch.cuda.current_stream(dev)
-        for s_ in lanes:
-            cur.wait_stream(s_)
-
     pending = None
-    for i in range(args.warmup):
+    for i in range(warmup):
         emb, pending = step(i, pending)
     if pending is not None:
         pending.wait()
@@ -330,9 +326,11 @@ def main():
     ev0.record()
     for s_ in lanes:
         s_.wait_event(ev0)
-    for i in range(args.steps):
+    for i in range(steps):
         emb, pending = step(i, pending)
-    join_lanes()
+    cur = torch.cuda.current_stream(dev)
+    for s_ in lanes:
+        cur.wait_stream(s_)
     ev1.record()
     if pending is not None:
         pending.wait()
@@ -345,43 +343,142 @@ def main():
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-    assert torch.isfinite(emb).all()
+    emb_timed = emb.clone()
+    checksum = float(emb_timed.double().abs().sum().item())
+    want = CHECKSUMS.get((args.model, dtype))
+    if not (checksum == checksum) or (want is not None and rank == 0 and abs(checksum - want) > 1e-9 * want):
+        raise SystemExit("embedding checksum %.12f of the timed configuration differs from the pinned %r" % (checksum, want))
 
+    out = None
     if rank == 0:
-        ms_per_step = wall * 1e3 / args.steps
-        value = world * BATCH * args.steps / wall
+        parity = None
+        if with_parity:
+            # (a) the timed configuration against the plain one: the same 256 images, 8 at a time, one stream, one context
+            model.set_contexts(1)
+            serial = torch.cat([model(x[i:i + 8]) for i in range(0, BATCH, 8)])
+            same = bool(torch.equal(serial, emb_timed))
+            parity = {"timed_output_bitwise_equals_serial_8_at_a_time": same, "checksum_abs_sum": checksum}
+            # (b) this dtype against the reference's own embeddings (golden inputs: 4 seeded + 2 real crops)
+            if args.model == "irv1":
+                gd = np.load(os.path.join(REPO, "tests", "golden", "irv1_seed0.npz"))
+                xg = torch.randn((6, 3, 160, 160), generator=torch.Generator().manual_seed(int(gd["input_seed"])))
+                xg[4:6] = torch.from_numpy(gd["real_inputs"].astype(np.float32))
+                yg = model(xg.to(dev).to(tdt)).cpu().numpy()
+                err = float(np.linalg.norm(yg - gd["embeddings"], axis=1).max())
+                parity.update({"l2_err_vs_reference_golden": err, "gate": 1e-4, "within_gate": bool(err <= 1e-4),
+                               "golden": "tests/golden/irv1_seed0.npz (embeddings produced by the reference's InceptionResnetV1)"})
+        ms_per_step = wall * 1e3 / steps
+        value = world * BATCH * steps / wall
         flop_per_step = 2.0 * macs * BATCH          # 2.8353 (IRv1) / 24.179 (IR-100) GFLOP per image
-        achieved = flop_per_step / (dev_ms / args.steps * 1e-3) / 1e12
-        peak = PEAK_BF16_TFLOPS if args.dtype != "f32" else 157.3
+        achieved = flop_per_step / (dev_ms / steps * 1e-3) / 1e12
+        peak = PEAK_BF16_TFLOPS if dtype != "f32" else 157.3
         alg, executed = model.flops_per_image()
         traffic = None   # HBM bytes per step from rocprofv3 PMC passes (collected separately, profiles/)
-        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
-        if args.dtype == "bf16" and args.model == "irv1" and os.path.exists(tpath):
+        tpath = os.path.join(REPO, "profiles", "%s_traffic.json" % ROUND)
+        if dtype == "bf16" and args.model == "irv1" and os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_step")
         out = {
             "metric": "embeddings/sec @ bs=256 (%s, %dx%d)" % (mname, size, size),
-            "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: %s embedding only, synthetic %dx%d %s, "
-                                   "bs=256 per GPU, generator weights seed 0" % (1 if args.model == "irv1" else 4, mname, size, size, args.dtype),
+                                   "bs=256 per GPU, generator weights seed 0" % (1 if args.model == "irv1" else 4, mname, size, size, dtype),
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "parallelism": "dp%d (frames sharded, all-gather of embeddings)" % world,
                        "lanes": len(lanes)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_note": "memory-side bytes per step, FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE from separate "
-                                         "rocprofv3 --pmc passes (profiles/r01_traffic.json); these L2 fabric counters include "
-                                         "Infinity-Cache hits, so HBM proper is at most this; algorithmic floor 87 MB",
-                         "kernel": "implicit-GEMM convolution kernels conv_igemm_dma / conv_patch / conv_igemm_ws (every launch of one "
-                                   "embed step, tile configuration per layer chosen by the create-time autotuner; device time by HIP events)",
+                                         "rocprofv3 --pmc passes (profiles/%s_traffic.json); these L2 fabric counters include "
+                                         "Infinity-Cache hits, so HBM proper is at most this; algorithmic floor 87 MB" % ROUND,
+                         "kernel": "every kernel of one embed step (fused inception-block kernels + implicit-GEMM convolutions; tile "
+                                   "configuration per layer chosen by the create-time autotuner); device time by HIP events; "
+                                   "achieved = algorithmic FLOP (2 x 1 417 662 304 MAC x 256) / device time per step; the 16-bit MFMA "
+                                   "peak is the yardstick for bf16, f16 and f16x2 (f16x2 issues 4 MFMAs per algorithmic one)",
                          "flop_per_step_algorithmic": flop_per_step,
                          "flop_per_image_executed": executed, "flop_per_image_counted_by_engine": alg,
-                         "device_ms_per_step": round(dev_ms / args.steps, 4)},
+                         "device_ms_per_step": round(dev_ms / steps, 4)},
         }
-        if not args.no_cpu_baseline and world == 1 and args.model == "irv1":
+        if parity is not None:
+            out["parity"] = parity
+        if want_cpu and world == 1 and args.model == "irv1":
             out["cpu_baseline"] = cpu_baseline()
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="all", choices=["all", "embed", "pipeline", "detect"],
+                    help="all (default): the embed headline leg + the other dtype legs + the pipeline leg in ONE JSON line; "
+                         "embed / pipeline / detect: that leg alone")
+    ap.add_argument("--embed-batch", type=int, default=256,
+                    help="pipeline workload: faces of consecutive frame batches are embedded together once this many wait "
+                         "(0: every frame batch on its own)")
+    ap.add_argument("--detectors", type=int, default=1, help="pipeline workload: detector handles (host threads) per GPU")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="streams / encoder activation contexts that consecutive embed launches rotate over (1: one stream; the "
+                         "embed workload's encoder then splits each batch over two internal streams instead); default 3 for the "
+                         "embed workload, 1 for the pipeline (measured best)")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f16x2", "f32"])
+    ap.add_argument("--legs", default="f16x2,f16,f32",
+                    help="workload all: further compute dtypes timed after the headline leg (comma list, '' for none)")
+    ap.add_argument("--model", default="irv1", choices=["irv1", "ir100"],
+                    help="irv1 = BASELINE configs[1] (default); ir100 = configs[4], the ArcFace IR-100 swap-in")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if args.workload == "detect":
+        return run_detect(args)
+
+    import torch
+    import torch.distributed as dist
+    from vn_celeb_face_recognition_amd import dist as vdist
+
+    rank, world, local = vdist.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    want_cpu = not args.no_cpu_baseline
+    emb_lanes = args.lanes if args.lanes > 0 else 3
+    pipe_lanes = args.lanes if args.lanes > 0 else 1
+
+    out = None
+    if args.workload in ("all", "embed"):
+        out = embed_leg(args, args.dtype, rank, world, dev, emb_lanes, args.steps, args.warmup, want_cpu)
+    if args.workload == "all" and args.model == "irv1":
+        # the other compute dtypes: shorter legs (the f32 leg runs ~7 ms steps), one rank each, no CPU baseline
+        legs = {}
+        for dt in [d for d in args.legs.split(",") if d and d != args.dtype]:
+            st = max(5, args.steps // (5 if dt == "f32" else 2))
+            try:
+                r = embed_leg(args, dt, rank, world, dev, emb_lanes, st, max(3, args.warmup // 2), False)
+            except Exception as e:    # a failing side leg must not take the headline line with it
+                r = {"error": "%s: %s" % (type(e).__name__, e)}
+            if rank == 0:
+                legs[dt] = r if "error" in r else {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "parity") if k in r}
+        if rank == 0:
+            out["legs"] = legs
+    if args.workload in ("all", "pipeline"):
+        st = args.steps if args.workload == "pipeline" else max(10, args.steps // 2)
+        try:
+            p = pipeline_leg(args, rank, world, local, st, args.warmup, pipe_lanes, want_cpu)
+        except Exception as e:
+            if args.workload == "pipeline":
+                raise
+            p = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            if args.workload == "pipeline":
+                out = p
+            else:
+                out["pipeline"] = p
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

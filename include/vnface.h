@@ -24,7 +24,7 @@
  *     vnf_last_error() returns a thread-local message for the last failure;
  *   - the caller owns all input/output buffers; the library owns handles, packed weights and
  *     workspaces (allocated at create time, sized by max_batch; nothing is allocated on the
- *     launch path);
+ *     launch path -- the one exception is documented at vnf_encoder_set_contexts);
  *   - a handle is bound to the device that was current at create time and is NOT thread-safe
  *     (one host thread per GPU / rank);
  *   - all work is enqueued on the caller's hipStream_t (passed as void*); calls do not
@@ -53,6 +53,7 @@ extern "C" {
 #define VNF_F16 2
 #define VNF_I64 3
 #define VNF_U8 4
+#define VNF_F16X2 5 /* compute dtype only: fp32 values kept as (hi, lo) pairs of halves (split-f16) */
 
 /* encoder architectures */
 #define VNF_ARCH_IRV1 0   /* InceptionResnetV1, 160x160 input, L2-normalised 512-d output */
@@ -75,8 +76,10 @@ const char* vnf_version(void);
 int vnf_destroy(vnf_handle h);
 
 /* encoders --------------------------------------------------------------------------------- */
-/* compute_dtype: VNF_BF16 | VNF_F16 (MFMA 16x16x32, fp32 accumulate) or VNF_F32 (exact-f32
- * MFMA 16x16x4, the <=1e-4 parity path). */
+/* compute_dtype: VNF_BF16 | VNF_F16 (MFMA 16x16x32 on 16-bit storage, fp32 accumulate);
+ * VNF_F16X2 (split-f16: every weight and activation is an (hi, lo) pair of halves, products
+ * expanded on the same 16-bit MFMA -- meets the <=1e-4 embedding gate at several times the
+ * rate of the exact path); VNF_F32 (exact-f32 MFMA 16x16x4, bit-for-bit an fp32 fma chain). */
 int vnf_encoder_create(int arch, const vnf_tensor_desc* weights, int n_weights, int compute_dtype,
                        int max_batch, vnf_handle* out);
 /* x: device pointer, (N,3,S,S) NCHW, already normalised, dtype VNF_F32 | VNF_BF16 | VNF_F16.
@@ -122,13 +125,18 @@ typedef struct {
   int32_t select_largest;  /* mtcnn.py:203: order boxes by area, descending */
   int32_t max_batch;       /* frames per call */
   int32_t max_height, max_width;
-  int32_t max_candidates;  /* capacity of the per-call candidate tables (0 = default) */
+  int32_t max_candidates;  /* reserved (must be 0): the candidate tables are compile-time sized -- 4096 P-Net cells
+                            * above threshold per (pyramid level, frame), 8192 per frame into the cross-scale NMS,
+                            * 2048 survivors per stage and frame; a frame that exceeds them fails the call with
+                            * VNF_E_CAPACITY (never a silent truncation) */
 } vnf_mtcnn_cfg;
 
 int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const vnf_tensor_desc* rnet, int n_rnet,
                      const vnf_tensor_desc* onet, int n_onet, const vnf_mtcnn_cfg* cfg, vnf_handle* out);
 /* frames: device (B,H,W,3) uint8 RGB.  Results stay on the device for vnf_align and are also
- * copied to the caller's host arrays (this call synchronises the stream once, at the end):
+ * copied to the caller's host arrays.  The call synchronises the stream up to three times: after stage 1
+ * and after stage 2 to size the next stage's launches from the candidate counts (the stage boundaries of
+ * detect_face.py:25-185), and at the end for the results:
  *   counts[B]            faces per frame
  *   boxes[max_out*4]     x1,y1,x2,y2 fp32, frames concatenated in order
  *   probs[max_out]
@@ -145,11 +153,26 @@ int vnf_mtcnn_detect(vnf_handle h, const uint8_t* frames, int b, int height, int
 int vnf_mtcnn_results_device(vnf_handle h, int32_t* frame_idx, float* boxes, float* probs, float* points,
                              int max_out, void* stream);
 
+/* measurement hook (bench.py roofline): one detection with HIP events between the cascade's stages on
+ * `stream`; report receives one text line per stage, "name milliseconds algorithmic_bytes" (pyramid,
+ * pnet_conv1_pool, pnet_conv2, pnet_conv3_heads, nms_stage1, host_sync_1, crop_resize_24, rnet, ...).
+ * Synchronises. */
+int vnf_mtcnn_stage_times(vnf_handle h, const uint8_t* frames, int b, int height, int width,
+                          char* report, int64_t capacity, void* stream);
+
 /* staged parity hook: runs the cascade on frame 0 and copies one pyramid level (3,Hs,Ws), its
  * P-Net face-probability map (oh,ow) and regression map (4,oh,ow) to host arrays.
  * dims receives {Hs, Ws, oh, ow}.  Synchronises. */
 int vnf_mtcnn_debug_pnet(vnf_handle h, const uint8_t* frames, int height, int width, int level,
                          float* level_out, float* prob_out, float* reg_out, int32_t dims[4], void* stream);
+
+/* staged parity hook for the O-stage decode alone (detect_face.py:148-169, mtcnn.py:334-340): threshold,
+ * landmark decode, bbreg, "Min" NMS and the final area ordering on a caller-made single-frame table --
+ * boxes (n,4) host fp32 (before bbreg), onet_out (n,15) host fp32 [prob, reg0..3, lm_x0..4, lm_y0..4];
+ * fin_out (max_out,15) host rows [x1,y1,x2,y2,score, (x,y) x 5].  Lets a test inject exactly tied scores.
+ * Synchronises. */
+int vnf_mtcnn_debug_stage3(vnf_handle h, const float* boxes, const float* onet_out, int n, float* fin_out,
+                           int max_out, int32_t* n_out, void* stream);
 
 /* alignment -------------------------------------------------------------------------------- */
 /* For each of n faces: crop rectangle from its box (demo_image.py:179-182), landmarks moved by

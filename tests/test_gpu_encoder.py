@@ -164,3 +164,45 @@ def test_activation_contexts_let_calls_on_different_streams_overlap_without_chan
         ready.synchronize()
         got[i] = emb.cpu().numpy()
     assert sorted(got) == list(range(6)) and all(np.array_equal(got[i], want[i % 3]) for i in got)
+
+
+def test_irv1_split_f16_meets_the_1e4_gate_on_16bit_mfma(irv1_sd):
+    """compute_dtype="f16x2": every weight / activation is an (hi, lo) pair of halves and each product is expanded on
+    v_mfma_f32_16x16x32_f16 -- a 16-bit-operand MFMA path that must sit inside the north-star gate (<= 1e-4 L2 against the
+    reference's own embeddings), with every stage tap within 1e-4 of the fp32 oracle (tolerance relative to the tap's
+    scale, as for the exact-f32 path)."""
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    from oracle import irv1
+    g, x = _golden_inputs()
+    m = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype="f16x2", max_batch=8).eval()
+    y = m(x.cuda()).cpu().numpy()
+    err = np.linalg.norm(y - g["embeddings"], axis=1)
+    print("irv1 f16x2: L2 error vs reference golden", err)
+    assert err.max() <= 1e-4, err
+    x3 = seeded_normal((3, 3, 160, 160), 99)
+    taps = {}
+    ref = irv1.irv1_forward(irv1_sd, x3, taps=taps).numpy()
+    y3 = m(x3.cuda()).cpu().numpy()
+    table = []
+    for name in ["conv2d_1a", "conv2d_2a", "conv2d_2b", "maxpool_3a", "conv2d_3b", "conv2d_4a", "conv2d_4b",
+                 "repeat_1", "mixed_6a", "repeat_2", "mixed_7a", "repeat_3", "block8"]:
+        got, want = m.tap(name, 3), taps[name].numpy()
+        assert got.shape == want.shape, name
+        e = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+        table.append((name, e))
+        assert e <= 1e-4, (name, e)
+    print("irv1 f16x2 per-stage max error / scale:", ", ".join("%s %.1e" % t for t in table))
+    assert np.linalg.norm(y3 - ref, axis=1).max() <= 1e-4
+    # 16-bit inputs are accepted too (they are exactly representable in the split type)
+    yb = m(x.cuda().to(torch.float16)).cpu().numpy()
+    assert np.isfinite(yb).all()
+
+
+def test_ir100_split_f16_matches_reference_golden():
+    from vn_celeb_face_recognition_amd.models import iresnet100
+    g = np.load(os.path.join(GOLDEN, "ir100_seed0.npz"))
+    x = seeded_normal((2, 3, 112, 112), g["input_seed"])
+    m = iresnet100(pretrained=False, compute_dtype="f16x2", max_batch=2).to("cuda:0").eval()
+    y = m(x.cuda()).cpu().numpy()
+    err = np.linalg.norm(y - g["features"], axis=1) / np.linalg.norm(g["features"], axis=1)
+    assert err.max() <= 1e-4, err

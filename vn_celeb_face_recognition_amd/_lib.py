@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvnface.so")
 
-VNF_F32, VNF_BF16, VNF_F16, VNF_I64, VNF_U8 = 0, 1, 2, 3, 4
+VNF_F32, VNF_BF16, VNF_F16, VNF_I64, VNF_U8, VNF_F16X2 = 0, 1, 2, 3, 4, 5
 VNF_ARCH_IRV1, VNF_ARCH_IR100 = 0, 1
 
 
@@ -50,6 +50,8 @@ SIGNATURES = {
                               ctypes.POINTER(TensorDesc), _I, ctypes.POINTER(MtcnnCfg), ctypes.POINTER(_P)]),
     "vnf_mtcnn_detect": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, ctypes.POINTER(ctypes.c_int32), _P]),
     "vnf_mtcnn_results_device": (_I, [_P, _P, _P, _P, _P, _I, _P]),
+    "vnf_mtcnn_stage_times": (_I, [_P, _P, _I, _I, _I, ctypes.c_char_p, ctypes.c_int64, _P]),
+    "vnf_mtcnn_debug_stage3": (_I, [_P, _P, _P, _I, _P, _I, ctypes.POINTER(ctypes.c_int32), _P]),
     "vnf_mtcnn_debug_pnet": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _P]),
     "vnf_align": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _P]),
 }

@@ -31,18 +31,21 @@ __device__ __forceinline__ int sat_int(double v) {
 
 struct Tmpl5 { float v[10]; };  // the 5-point template travels as a kernel argument: no H2D copy on the launch path
 
-__global__ void align_setup_kernel(const int32_t* __restrict__ frame_idx, const float* __restrict__ boxes,
-                                   const float* __restrict__ points, const Tmpl5 tmpl, int n, int H,
-                                   int W, FaceXf* __restrict__ xf) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// crop rectangle + inverse similarity of face i (one thread per workgroup computes it into LDS)
+__device__ __forceinline__ void face_xf(const int32_t* __restrict__ frame_idx, const float* __restrict__ boxes,
+                                        const float* __restrict__ points, const Tmpl5& tmpl, int i, int B, int H, int W,
+                                        FaceXf& o) {
   const float* b = boxes + 4 * i;
-  FaceXf o;
-  o.frame = frame_idx ? frame_idx[i] : 0;
+  const int fr = frame_idx ? frame_idx[i] : 0;
+  o.frame = min(max(fr, 0), B - 1);
   // python int() truncates toward zero
   const int x1 = max((int)b[0], 0), y1 = max((int)b[1], 0);
   const int x2 = min((int)(b[2] + 1.0f), W), y2 = min((int)(b[3] + 1.0f), H);
-  o.x1 = x1; o.y1 = y1; o.cw = x2 - x1; o.ch = y2 - y1;
+  // a box entirely outside the frame (or a frame index outside the batch) is an empty crop: every tap is border
+  // (value 0), as warping a zero-size source would be
+  o.x1 = min(x1, W); o.y1 = min(y1, H);
+  o.cw = (fr == o.frame) ? max(x2 - x1, 0) : 0;
+  o.ch = max(y2 - y1, 0);
   // landmarks relative to the float box corner (fp32 subtraction, as numpy does on float32 arrays)
   double px[5], py[5], qx[5], qy[5];
   double pmx = 0, pmy = 0, qmx = 0, qmy = 0;
@@ -62,7 +65,8 @@ __global__ void align_setup_kernel(const int32_t* __restrict__ frame_idx, const 
     var += sx * sx + sy * sy;
   }
   a11 /= 5; a12 /= 5; a21 /= 5; a22 /= 5; var /= 5;
-  const double sc = (a11 + a22) / var, ss = (a21 - a12) / var;
+  // coincident landmarks (var == 0) have no similarity: a singular map (everything samples one point) instead of NaN
+  const double sc = var > 0 ? (a11 + a22) / var : 0.0, ss = var > 0 ? (a21 - a12) / var : 0.0;
   double M[6] = {sc, -ss, qmx - (sc * pmx - ss * pmy), ss, sc, qmy - (ss * pmx + sc * pmy)};
   // cv::warpAffine: invert the forward matrix in double
   double D = M[0] * M[4] - M[1] * M[3];
@@ -73,18 +77,24 @@ __global__ void align_setup_kernel(const int32_t* __restrict__ frame_idx, const 
   const double b2 = -M[3] * M[2] - M[4] * M[5];
   M[2] = b1; M[5] = b2;
   for (int k = 0; k < 6; ++k) o.m[k] = M[k];
-  xf[i] = o;
 }
 
 template <typename TN>
-__global__ void align_warp_kernel(const uint8_t* __restrict__ frames, int H, int W, const FaceXf* __restrict__ xf, int n,
-                                  int S, uint8_t* __restrict__ out_u8, TN* __restrict__ out_norm) {
-  const size_t total = (size_t)n * S * S;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int x = (int)(i % S);
-    const int y = (int)((i / S) % S);
-    const int f = (int)(i / ((size_t)S * S));
-    const FaceXf t = xf[f];
+__global__ void __launch_bounds__(256) align_warp_kernel(const uint8_t* __restrict__ frames, int B, int H, int W,
+                                                         const int32_t* __restrict__ frame_idx, const float* __restrict__ boxes,
+                                                         const float* __restrict__ points, const Tmpl5 tmpl, int S,
+                                                         uint8_t* __restrict__ out_u8, TN* __restrict__ out_norm) {
+  // blockIdx.y = face; its workgroups (blockIdx.x) each derive the face's transform (a few hundred fp64 operations on
+  // one lane) instead of reading a table a setup launch would have to allocate and fill
+  __shared__ FaceXf s_xf;
+  const int f = blockIdx.y;
+  if (threadIdx.x == 0) face_xf(frame_idx, boxes, points, tmpl, f, B, H, W, s_xf);
+  __syncthreads();
+  const FaceXf t = s_xf;
+  const int per_face = S * S;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < per_face; q += gridDim.x * blockDim.x) {
+    const int x = q % S, y = q / S;
+    const size_t i = (size_t)f * per_face + q;
     constexpr int AB_BITS = 10, INTER_BITS = 5, AB_SCALE = 1 << AB_BITS, TAB = 1 << INTER_BITS;
     constexpr int round_delta = AB_SCALE / TAB / 2;
     const int adelta = sat_int(t.m[0] * x * AB_SCALE);
@@ -131,33 +141,27 @@ extern "C" int vnf_align(const uint8_t* frames, int b, int height, int width, co
   if (!frames || !boxes || !points || !template5x2 || n < 0 || s <= 0 || b <= 0 || (!faces_u8 && !faces_norm))
     return fail(VNF_E_INVALID, "vnf_align: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  // per-call scratch (n * 72 B) from the stream-ordered allocator: no sync
-  FaceXf* xf = nullptr;
-  Tmpl5 tmpl;
+  Tmpl5 tmpl;  // travels as a kernel argument; no workspace, nothing allocated or copied on the launch path
   for (int i = 0; i < 10; ++i) tmpl.v[i] = template5x2[i];
-  VNF_HIP(hipMallocAsync((void**)&xf, sizeof(FaceXf) * (size_t)n, st));
-  hipLaunchKernelGGL(align_setup_kernel, dim3((n + 63) / 64), dim3(64), 0, st, frame_idx, boxes, points, tmpl, n, height,
-                     width, xf);
-  const size_t total = (size_t)n * s * s;
-  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  if (n > 65535) return fail(VNF_E_CAPACITY, "vnf_align: at most 65535 faces per call");
+  const int per_face = (s * s + 255) / 256;
+  const dim3 grid(per_face < 8 ? per_face : 8, n);
   switch (faces_norm ? norm_dtype : VNF_F32) {
     case VNF_F32:
-      hipLaunchKernelGGL(align_warp_kernel<float>, dim3(blocks), dim3(256), 0, st, frames, height, width, xf, n, s,
-                         faces_u8, (float*)faces_norm);
+      hipLaunchKernelGGL(align_warp_kernel<float>, grid, dim3(256), 0, st, frames, b, height, width, frame_idx, boxes, points,
+                         tmpl, s, faces_u8, (float*)faces_norm);
       break;
     case VNF_BF16:
-      hipLaunchKernelGGL(align_warp_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, frames, height, width, xf, n, s,
-                         faces_u8, (__bf16*)faces_norm);
+      hipLaunchKernelGGL(align_warp_kernel<__bf16>, grid, dim3(256), 0, st, frames, b, height, width, frame_idx, boxes, points,
+                         tmpl, s, faces_u8, (__bf16*)faces_norm);
       break;
     case VNF_F16:
-      hipLaunchKernelGGL(align_warp_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, frames, height, width, xf, n, s,
-                         faces_u8, (_Float16*)faces_norm);
+      hipLaunchKernelGGL(align_warp_kernel<_Float16>, grid, dim3(256), 0, st, frames, b, height, width, frame_idx, boxes,
+                         points, tmpl, s, faces_u8, (_Float16*)faces_norm);
       break;
     default:
-      (void)hipFreeAsync(xf, st);
       return fail(VNF_E_INVALID, "vnf_align: bad norm_dtype");
   }
   VNF_HIP(hipGetLastError());
-  VNF_HIP(hipFreeAsync(xf, st));
   return VNF_OK;
 }

@@ -46,13 +46,13 @@ int vnf_encoder_create(int arch, const vnf_tensor_desc* weights, int n_weights, 
                        vnf_handle* out) {
   API_GUARD_BEGIN
   if (!out || !weights || n_weights <= 0 || max_batch <= 0) return fail(VNF_E_INVALID, "bad argument");
-  if (compute_dtype != VNF_F32 && compute_dtype != VNF_BF16 && compute_dtype != VNF_F16)
-    return fail(VNF_E_INVALID, "compute_dtype must be VNF_F32, VNF_BF16 or VNF_F16");
+  if (compute_dtype != VNF_F32 && compute_dtype != VNF_BF16 && compute_dtype != VNF_F16 && compute_dtype != VNF_F16X2)
+    return fail(VNF_E_INVALID, "compute_dtype must be VNF_F32, VNF_BF16, VNF_F16 or VNF_F16X2");
   *out = nullptr;
   Encoder* e = new Encoder();
   e->kind = 1;
   e->arch = arch;
-  e->dtype = compute_dtype;  // VNF_F32/BF16/F16 == vnf::F32/BF16/F16
+  e->dtype = compute_dtype;  // VNF_F32/BF16/F16/F16X2 == vnf::F32/BF16/F16/F16X2
   e->max_batch = max_batch;
   (void)hipGetDevice(&e->device);
   WeightMap wm(weights, n_weights);

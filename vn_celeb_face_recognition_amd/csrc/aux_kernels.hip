@@ -1,6 +1,7 @@
 // HBM-bound helper kernels around the convolution core: layout packing, pooling, L2 norm.
 // All are coalesced streaming kernels (16-byte accesses along the NHWC channel axis).
 #include "kernels.h"
+#include "split_f16.h"
 
 namespace vnf {
 
@@ -42,6 +43,7 @@ static hipError_t pack_dispatch_out(const void* x, void* out, int dtype, int n, 
     case BF16: hipLaunchKernelGGL((pack_input_kernel<TI, __bf16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (__bf16*)out, n, hw); break;
     case F16: hipLaunchKernelGGL((pack_input_kernel<TI, _Float16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (_Float16*)out, n, hw); break;
     case F32: hipLaunchKernelGGL((pack_input_kernel<TI, float>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (float*)out, n, hw); break;
+    case F16X2: hipLaunchKernelGGL((pack_input_kernel<TI, sf16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (sf16*)out, n, hw); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -106,6 +108,7 @@ static hipError_t stem_dispatch_out(const void* x, void* y, int ldy, int dtype, 
     case BF16: hipLaunchKernelGGL((stem_conv1a_kernel<TI, __bf16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (__bf16*)y, ldy, n, wt); break;
     case F16: hipLaunchKernelGGL((stem_conv1a_kernel<TI, _Float16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (_Float16*)y, ldy, n, wt); break;
     case F32: hipLaunchKernelGGL((stem_conv1a_kernel<TI, float>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (float*)y, ldy, n, wt); break;
+    case F16X2: hipLaunchKernelGGL((stem_conv1a_kernel<TI, sf16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (sf16*)y, ldy, n, wt); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -168,6 +171,7 @@ hipError_t launch_maxpool3s2(const void* x, int ldx, void* y, int ldy, int dtype
     case BF16: hipLaunchKernelGGL(maxpool3s2_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)x, ldx, (__bf16*)y, ldy, n, H, W, C); break;
     case F16: hipLaunchKernelGGL(maxpool3s2_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)x, ldx, (_Float16*)y, ldy, n, H, W, C); break;
     case F32: hipLaunchKernelGGL(maxpool3s2_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, n, H, W, C); break;
+    case F16X2: hipLaunchKernelGGL(maxpool3s2_kernel<sf16>, dim3(blocks), dim3(256), 0, s, (const sf16*)x, ldx, (sf16*)y, ldy, n, H, W, C); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -222,6 +226,7 @@ hipError_t launch_maxpool_ceil(const void* x, int ldx, void* y, int ldy, int dty
     case BF16: hipLaunchKernelGGL(maxpool_ceil_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)x, ldx, (__bf16*)y, ldy, n, H, W, C, k); break;
     case F16: hipLaunchKernelGGL(maxpool_ceil_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)x, ldx, (_Float16*)y, ldy, n, H, W, C, k); break;
     case F32: hipLaunchKernelGGL(maxpool_ceil_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, n, H, W, C, k); break;
+    case F16X2: hipLaunchKernelGGL(maxpool_ceil_kernel<sf16>, dim3(blocks), dim3(256), 0, s, (const sf16*)x, ldx, (sf16*)y, ldy, n, H, W, C, k); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -248,6 +253,7 @@ hipError_t launch_avgpool(const void* x, int ldx, void* y, int dtype, int n, int
     case BF16: hipLaunchKernelGGL(avgpool_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)x, ldx, (__bf16*)y, n, HW, C); break;
     case F16: hipLaunchKernelGGL(avgpool_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)x, ldx, (_Float16*)y, n, HW, C); break;
     case F32: hipLaunchKernelGGL(avgpool_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, ldx, (float*)y, n, HW, C); break;
+    case F16X2: hipLaunchKernelGGL(avgpool_kernel<sf16>, dim3(blocks), dim3(256), 0, s, (const sf16*)x, ldx, (sf16*)y, n, HW, C); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -334,6 +340,7 @@ hipError_t launch_nhwc_to_nchw_f32(const void* x, int ldx, int dtype, float* y, 
     case BF16: hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)x, ldx, y, n, HW, C); break;
     case F16: hipLaunchKernelGGL(nhwc_to_nchw_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)x, ldx, y, n, HW, C); break;
     case F32: hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, ldx, y, n, HW, C); break;
+    case F16X2: hipLaunchKernelGGL(nhwc_to_nchw_kernel<sf16>, dim3(blocks), dim3(256), 0, s, (const sf16*)x, ldx, y, n, HW, C); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -2,6 +2,7 @@
 // kernel + register-staged fallback; conv_patch.hip: LDS-resident input patch kernel).
 #pragma once
 #include "kernels.h"
+#include "split_f16.h"
 
 namespace vnf {
 
@@ -55,6 +56,19 @@ __device__ __forceinline__ void mma_chunk<float>(f32x4_t& acc, const uint4& wf, 
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[3], x4[3], acc, 0, 0, 0);
 }
 
+template <>
+__device__ __forceinline__ void mma_chunk<sf16>(f32x4_t& acc, const uint4& wf, const uint4& xf) {
+  // each operand chunk is 4 k values as (hi, lo) halves: slots [h0 l0 h1 l1 h2 l2 h3 l3].  The first MFMA pairs
+  // equal slots (sum hi*hi' + lo*lo'), the second pairs the weight chunk with the activation chunk's halves
+  // swapped inside every dword (sum hi*lo' + lo*hi'): together the full product of the two split values.
+  const uint4 xr = {(xf.x >> 16) | (xf.x << 16), (xf.y >> 16) | (xf.y << 16), (xf.z >> 16) | (xf.z << 16),
+                    (xf.w >> 16) | (xf.w << 16)};
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, wf), __builtin_bit_cast(f16x8_t, xf),
+                                               acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, wf), __builtin_bit_cast(f16x8_t, xr),
+                                               acc, 0, 0, 0);
+}
+
 template <typename T>
 __device__ __forceinline__ void load8(const char* p, float (&v)[8]);
 template <>
@@ -74,6 +88,16 @@ __device__ __forceinline__ void load8<float>(const char* p, float (&v)[8]) {
   f32x4_t a = *reinterpret_cast<const f32x4_t*>(p), b = *reinterpret_cast<const f32x4_t*>(p + 16);
 #pragma unroll
   for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+
+template <>
+__device__ __forceinline__ void load8<sf16>(const char* p, float (&v)[8]) {
+  f16x8_t a = *reinterpret_cast<const f16x8_t*>(p), b = *reinterpret_cast<const f16x8_t*>(p + 16);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = (float)a[2 * i] + (float)a[2 * i + 1];
+    v[4 + i] = (float)b[2 * i] + (float)b[2 * i + 1];
+  }
 }
 
 template <typename T>
@@ -97,6 +121,19 @@ __device__ __forceinline__ void store8<float>(char* p, const float (&v)[8]) {
   f32x4_t a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
   *reinterpret_cast<f32x4_t*>(p) = a;
   *reinterpret_cast<f32x4_t*>(p + 16) = b;
+}
+
+template <>
+__device__ __forceinline__ void store8<sf16>(char* p, const float (&v)[8]) {
+  f16x8_t a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const sf16 s0(v[i]), s1(v[4 + i]);
+    a[2 * i] = s0.hi; a[2 * i + 1] = s0.lo;
+    b[2 * i] = s1.hi; b[2 * i + 1] = s1.lo;
+  }
+  *reinterpret_cast<f16x8_t*>(p) = a;
+  *reinterpret_cast<f16x8_t*>(p + 16) = b;
 }
 
 // XCD-aware, bijective block -> tile map: blocks that share an XCD (same blockIdx % 8) walk

@@ -445,6 +445,7 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t s) {
     case BF16: return launch_typed<__bf16>(a, k, s);
     case F16: return launch_typed<_Float16>(a, k, s);
     case F32: return launch_typed<float>(a, k, s);
+    case F16X2: return launch_typed<sf16>(a, k, s);
   }
   return hipErrorInvalidValue;
 }

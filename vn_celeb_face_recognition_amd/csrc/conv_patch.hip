@@ -297,6 +297,7 @@ hipError_t launch_patch(const ConvArgs& a, const KArgs& k, int pcfg, hipStream_t
     case BF16: return launch_patch_typed<__bf16>(pcfg, kk, g.lds, s);
     case F16: return launch_patch_typed<_Float16>(pcfg, kk, g.lds, s);
     case F32: return launch_patch_typed<float>(pcfg, kk, g.lds, s);
+    case F16X2: return launch_patch_typed<sf16>(pcfg, kk, g.lds, s);
   }
   return hipErrorInvalidValue;
 }

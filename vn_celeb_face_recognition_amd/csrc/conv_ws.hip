@@ -291,6 +291,7 @@ hipError_t launch_ws(const ConvArgs& a, const KArgs& k, int wcfg, hipStream_t s)
     case BF16: return launch_ws_typed<__bf16>(wcfg, k, s);
     case F16: return launch_ws_typed<_Float16>(wcfg, k, s);
     case F32: return launch_ws_typed<float>(wcfg, k, s);
+    case F16X2: return launch_ws_typed<sf16>(wcfg, k, s);
   }
   return hipErrorInvalidValue;
 }

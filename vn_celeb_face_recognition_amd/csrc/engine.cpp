@@ -2,6 +2,7 @@
 // slices of a small set of device buffers (concat-free inception branches), and replays a
 // static plan of convolution / pooling launches on the caller's stream.
 #include "engine.h"
+#include "split_f16.h"
 
 #include <cmath>
 #include <cstdio>
@@ -75,6 +76,9 @@ void convert_to(int dtype, const float* src, void* dst, size_t n) {
   } else if (dtype == BF16) {
     uint16_t* d = (uint16_t*)dst;
     for (size_t i = 0; i < n; ++i) d[i] = f2bf16(src[i]);
+  } else if (dtype == F16X2) {
+    sf16* d = (sf16*)dst;
+    for (size_t i = 0; i < n; ++i) d[i] = sf16(src[i]);
   } else {
     _Float16* d = (_Float16*)dst;
     for (size_t i = 0; i < n; ++i) d[i] = (_Float16)src[i];

@@ -5,8 +5,9 @@
 
 namespace vnf {
 
-enum DType { F32 = 0, BF16 = 1, F16 = 2 };
-inline int dtype_size(int dt) { return dt == F32 ? 4 : 2; }
+// F16X2: split-f16 (hi, lo) pairs, split_f16.h -- fp32-class accuracy on the 16-bit MFMA (ids follow include/vnface.h)
+enum DType { F32 = 0, BF16 = 1, F16 = 2, F16X2 = 5 };
+inline int dtype_size(int dt) { return (dt == F32 || dt == F16X2) ? 4 : 2; }
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_PRELU = 2 };
 

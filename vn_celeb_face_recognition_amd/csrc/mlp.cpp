@@ -11,6 +11,11 @@ struct Mlp : HandleBase {
   Encoder enc;  // owns the packed layers and the three activation buffers
   int input_dim = 0, num_classes = 0, cpad = 0, max_batch = 0;
   int b_in = -1, b_h = -1, b_logit = -1;
+  // the handle has ONE set of activation buffers: calls issued on different streams (the pipeline's rotating embedding
+  // lanes) are ordered against each other through this event, so a later call cannot overwrite what an earlier one
+  // is still reading
+  hipEvent_t done = nullptr;
+  ~Mlp() override { if (done) (void)hipEventDestroy(done); }
 };
 
 int add_linear(Encoder& e, const std::string& name, const float* w, const float* b, int cin, int cout, int cout_pad,
@@ -63,11 +68,14 @@ extern "C" int vnf_classify(vnf_handle h, const float* emb, int f, float* logp_o
     if (!emb) return fail(VNF_E_INVALID, "vnf_classify: bad argument");
     hipStream_t s = (hipStream_t)stream;
     Encoder& e = m->enc;
+    if (m->done) VNF_HIP(hipStreamWaitEvent(s, m->done, 0));
+    else VNF_HIP(hipEventCreateWithFlags(&m->done, hipEventDisableTiming));
     VNF_HIP(hipMemcpyAsync(e.bufs[m->b_in].ptr, emb, (size_t)f * m->input_dim * 4, hipMemcpyDeviceToDevice, s));
     int r = e.run(nullptr, f, VNF_F32, nullptr, s);
     if (r != VNF_OK) return r;
     VNF_HIP(launch_logsoftmax_argmax((const float*)e.bufs[m->b_logit].ptr, m->cpad, m->num_classes, f, logp_out,
                                      argmax_out, prob_out, s));
+    VNF_HIP(hipEventRecord(m->done, s));
     return VNF_OK;
   } catch (const std::exception& ex) {
     return fail(VNF_E_INVALID, std::string("exception: ") + ex.what());

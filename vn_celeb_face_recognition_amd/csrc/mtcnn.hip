@@ -1422,9 +1422,25 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
   }
 }
 
+// per-stage device time + algorithmic bytes of one call (vnf_mtcnn_stage_times): events between the stages' launches
+struct StageProf {
+  std::vector<std::string> name;
+  std::vector<double> bytes;
+  std::vector<hipEvent_t> ev;
+  void mark(const char* n, double b, hipStream_t s) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    name.push_back(n); bytes.push_back(b); ev.push_back(e);
+  }
+  ~StageProf() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+};
+
 static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipStream_t s, std::vector<int>& cnt,
-                     std::vector<float>& fin) {
+                     std::vector<float>& fin, StageProf* prof = nullptr) {
   const vnf_mtcnn_cfg& cfg = m->cfg;
+  // a mark closes the stage named in it: its time is the span since the previous mark
+  auto mark = [&](const char* n, double bytes) { if (prof) prof->mark(n, bytes, s); };
   if (b > cfg.max_batch || H > cfg.max_height || W > cfg.max_width) return fail(VNF_E_CAPACITY, "mtcnn: frame batch exceeds handle capacity");
   LevelTable t = make_levels(H, W, cfg.min_face_size, (double)cfg.factor);
   m->last_table = t;
@@ -1439,6 +1455,7 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   const int B = b;
   const size_t nseg = (size_t)MAX_LEVELS * cfg.max_batch;
   VNF_HIP(hipMemsetAsync(m->cand_cnt, 0, (nseg * 2 + (size_t)cfg.max_batch * 3 + 16) * 4, s));
+  mark("begin", 0);
   {
     // bin sums must stay exact in fp32 (< 2^24): always true below 256x256-pixel bins
     const bool fast = (W * 3) % 16 == 0 && (size_t)W * 12 <= 64 * 1024 && ((reinterpret_cast<uintptr_t>(frames)) & 15) == 0;
@@ -1450,10 +1467,16 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
       hipLaunchKernelGGL(pyramid_kernel, dim3((t.tot_px + 255) / 256, B), dim3(256), 0, s, frames, H, W, t, m->lvl);
     }
   }
+  // algorithmic bytes per launch: what each kernel must read + write once (SURVEY.md 8d terms, from the level table)
+  const double fB = (double)B;
+  mark("pyramid", fB * ((double)H * W * 3 + (double)t.tot_px * 12));
   hipLaunchKernelGGL(pnet_conv1_pool_kernel, dim3((t.tot_p1 + 255) / 256, B), dim3(256), 0, s, m->lvl, t, m->pw, m->p1);
+  mark("pnet_conv1_pool", fB * ((double)t.tot_px * 12 + (double)t.tot_p1 * 40));
   hipLaunchKernelGGL(pnet_conv2_kernel, dim3((t.tot_c2 + 255) / 256, B), dim3(256), 0, s, m->p1, t, m->pw, m->c2);
+  mark("pnet_conv2", fB * ((double)t.tot_p1 * 40 + (double)t.tot_c2 * 64));
   hipLaunchKernelGGL(pnet_conv3_heads_kernel, dim3((t.tot_out + 255) / 256, B), dim3(256), 0, s, m->c2, t, m->pw,
                      cfg.thresholds[0], B, m->cand, m->cand_cnt, m->status, m->prob_dbg, m->reg_dbg);
+  mark("pnet_conv3_heads", fB * (double)t.tot_c2 * 64);
   const size_t lds_scale = (size_t)CAP_SCALE * 8 + KEEP * 20 + 256 * 20;
   const size_t lds_img = (size_t)CAP_IMG * 8 + KEEP * 20 + 256 * 20;
   hipLaunchKernelGGL(nms_scale_kernel, dim3(t.n, B), dim3(256), lds_scale, s, m->cand, m->cand_cnt, t, B, 0.5f, m->keep1,
@@ -1461,6 +1484,7 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   hipLaunchKernelGGL(nms_image_kernel, dim3(B), dim3(256), lds_img, s, m->keep1, m->keep1_cnt, t, B, 0.7f, W, H, m->rows,
                      m->row_cnt, m->status);
   VNF_HIP(hipGetLastError());
+  mark("nms_stage1", 0);
   const int ncnt = cfg.max_batch * 3 + 16;
   int* const h = m->h_pin;  // pinned: the copy is a true async DMA, the only wait is the stream synchronisation
   auto read_counts = [&]() -> int {
@@ -1473,6 +1497,7 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   };
   int r = read_counts();
   if (r != VNF_OK) return r;
+  mark("host_sync_1", 0);
   int max2 = 0;
   for (int i = 0; i < B; ++i) max2 = std::max(max2, h[i]);
   if (max2 == 0) return VNF_OK;
@@ -1491,8 +1516,10 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
     for (int c0 = 0; c0 < total; c0 += cap) {
       const int n = std::min(cap, total - c0);
       crop(rws, cntp, maxc, S, (float*)enc->bufs[0].ptr, m->offs, c0, n);
+      mark(S == 24 ? "crop_resize_24" : "crop_resize_48", (double)n * S * S * 16);  // output bytes only (NHWC4 fp32)
       int rc = enc->run(nullptr, n, VNF_F32, nullptr, s);
       if (rc != VNF_OK) return rc;
+      mark(S == 24 ? "rnet" : "onet", 0);
       hipLaunchKernelGGL(heads_scatter_kernel, dim3((maxc + 63) / 64, B), dim3(64), 0, s, (const float*)enc->bufs.back().ptr, hw,
                          m->offs, cntp, c0, n, dst, nf);
     }
@@ -1511,8 +1538,10 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   hipLaunchKernelGGL(stage2_post_kernel, dim3(B), dim3(256), lds_post, s, m->rows, m->row_cnt, m->rout, cfg.thresholds[1], 0.7f,
                      W, H, m->rows3, m->row3_cnt, m->status);
   VNF_HIP(hipGetLastError());
+  mark("stage2_post", 0);
   r = read_counts();
   if (r != VNF_OK) return r;
+  mark("host_sync_2", 0);
   int max3 = 0;
   for (int i = 0; i < B; ++i) max3 = std::max(max3, h[cfg.max_batch + i]);
   if (max3 == 0) return VNF_OK;
@@ -1531,8 +1560,10 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   m->last_b = B;
   hipLaunchKernelGGL(pack_results_kernel, dim3(B), dim3(256), 0, s, m->row_cnt, ncnt, m->fin, m->fin_cnt, B, m->stage);
   VNF_HIP(hipGetLastError());
+  mark("stage3_post", 0);
   VNF_HIP(hipMemcpyAsync(h, m->stage, ((size_t)ncnt + (size_t)B * FIN_FAST * 15) * 4, hipMemcpyDeviceToHost, s));
   VNF_HIP(hipStreamSynchronize(s));
+  mark("readback", 0);
   {
     const int st = h[cfg.max_batch * 3];
     if (st & (ST_OVER_SCALE | ST_OVER_IMG | ST_OVER_KEEP))
@@ -1583,6 +1614,37 @@ extern "C" int vnf_mtcnn_detect(vnf_handle h, const uint8_t* frames, int b, int 
   }
 }
 
+// One detection with HIP events between the cascade's stages (on the caller's stream): a text table, one line per
+// stage "name ms algorithmic_bytes" (bytes 0 where the stage is not bandwidth-priced).  Synchronises.
+extern "C" int vnf_mtcnn_stage_times(vnf_handle h, const uint8_t* frames, int b, int height, int width, char* report,
+                                     int64_t capacity, void* stream) {
+  try {
+    HandleBase* hb = reinterpret_cast<HandleBase*>(h);
+    if (!hb || hb->kind != 3) return fail(VNF_E_INVALID, "not an MTCNN handle");
+    if (!frames || b <= 0 || !report || capacity <= 0) return fail(VNF_E_INVALID, "vnf_mtcnn_stage_times: bad argument");
+    Mtcnn* m = static_cast<Mtcnn*>(hb);
+    std::vector<int> cnt;
+    std::vector<float> fin;
+    StageProf prof;
+    int r = mtcnn_run(m, frames, b, height, width, (hipStream_t)stream, cnt, fin, &prof);
+    if (r != VNF_OK) return r;
+    VNF_HIP(hipStreamSynchronize((hipStream_t)stream));
+    std::string rep;
+    char line[160];
+    for (size_t i = 1; i < prof.ev.size(); ++i) {
+      float ms = 0;
+      VNF_HIP(hipEventElapsedTime(&ms, prof.ev[i - 1], prof.ev[i]));
+      snprintf(line, sizeof line, "%s %.6f %.0f\n", prof.name[i].c_str(), ms, prof.bytes[i]);
+      rep += line;
+    }
+    strncpy(report, rep.c_str(), (size_t)capacity - 1);
+    report[capacity - 1] = 0;
+    return VNF_OK;
+  } catch (const std::exception& ex) {
+    return fail(VNF_E_INVALID, std::string("exception: ") + ex.what());
+  }
+}
+
 extern "C" int vnf_mtcnn_results_device(vnf_handle h, int32_t* frame_idx, float* boxes, float* probs, float* points,
                                         int max_out, void* stream) {
   HandleBase* hb = reinterpret_cast<HandleBase*>(h);
@@ -1594,6 +1656,45 @@ extern "C" int vnf_mtcnn_results_device(vnf_handle h, int32_t* frame_idx, float*
                      frame_idx, boxes, probs, points);
   VNF_HIP(hipGetLastError());
   return VNF_OK;
+}
+
+// Staged-parity hook for the O-stage decode alone (detect_face.py:148-169 + mtcnn.py:334-340): runs stage3_post_kernel
+// on a caller-made candidate table of ONE frame -- boxes (n,4) before bbreg and the O-Net outputs (n,15: face
+// probability, 4 regression values, 5 x-landmarks, 5 y-landmarks) -- so a test can inject exactly tied scores.
+// fin_out receives up to max_out rows [x1,y1,x2,y2,score, 10 landmark coordinates].  Synchronises.
+extern "C" int vnf_mtcnn_debug_stage3(vnf_handle h, const float* boxes, const float* onet_out, int n, float* fin_out,
+                                      int max_out, int32_t* n_out, void* stream) {
+  try {
+    HandleBase* hb = reinterpret_cast<HandleBase*>(h);
+    if (!hb || hb->kind != 3) return fail(VNF_E_INVALID, "not an MTCNN handle");
+    if (!boxes || !onet_out || n < 0 || n > KEEP || !fin_out || !n_out) return fail(VNF_E_INVALID, "vnf_mtcnn_debug_stage3: bad argument");
+    Mtcnn* m = static_cast<Mtcnn*>(hb);
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<Row> rows((size_t)std::max(n, 1));
+    for (int i = 0; i < n; ++i) {
+      Row r{};
+      r.x1 = boxes[i * 4]; r.y1 = boxes[i * 4 + 1]; r.x2 = boxes[i * 4 + 2]; r.y2 = boxes[i * 4 + 3];
+      rows[i] = r;
+    }
+    VNF_HIP(hipMemcpyAsync(m->rows3, rows.data(), (size_t)n * sizeof(Row), hipMemcpyHostToDevice, s));
+    VNF_HIP(hipMemcpyAsync(m->oout, onet_out, (size_t)n * 15 * 4, hipMemcpyHostToDevice, s));
+    VNF_HIP(hipMemcpyAsync(m->row3_cnt, &n, 4, hipMemcpyHostToDevice, s));
+    VNF_HIP(hipMemsetAsync(m->status, 0, 4, s));
+    const size_t lds_post = (size_t)KEEP * 28 + 256 * 20 + KEEP * 16;
+    hipLaunchKernelGGL(stage3_post_kernel, dim3(1), dim3(256), lds_post, s, m->rows3, m->row3_cnt, m->oout, m->cfg.thresholds[2],
+                       0.7f, m->cfg.select_largest, m->fin, m->fin_cnt, m->status);
+    VNF_HIP(hipGetLastError());
+    int nk = 0;
+    VNF_HIP(hipMemcpyAsync(&nk, m->fin_cnt, 4, hipMemcpyDeviceToHost, s));
+    VNF_HIP(hipStreamSynchronize(s));
+    *n_out = nk;
+    if (nk > max_out) return fail(VNF_E_CAPACITY, "vnf_mtcnn_debug_stage3: more rows than max_out");
+    VNF_HIP(hipMemcpy(fin_out, m->fin, (size_t)nk * 15 * 4, hipMemcpyDeviceToHost));
+    m->last_b = 0;
+    return VNF_OK;
+  } catch (const std::exception& ex) {
+    return fail(VNF_E_INVALID, std::string("exception: ") + ex.what());
+  }
 }
 
 // Staged-parity hook: dense P-Net maps of one pyramid level for frame 0 of a batch (test use).

@@ -146,6 +146,46 @@ class MTCNN:
             n = n_out.value
             return counts.tolist(), boxes[:n], probs[:n], points[:n].reshape(n, 5, 2)
 
+    def stage_times(self, frames, reps=5):
+        """Per-stage device time of one detection (vnf_mtcnn_stage_times: HIP events between the stages on the
+        current stream).  frames: (B,H,W,3) u8 cuda.  Returns {stage: {"ms": median over reps, "bytes": algorithmic
+        bytes of the launch}}; kernels stages carry their kernel's name (pyramid, pnet_conv1_pool, ...)."""
+        b, h, w, _ = frames.shape
+        hd = self._ensure(b, h, w)
+        lib = _lib.load()
+        acc = {}
+        for _ in range(reps):
+            buf = ctypes.create_string_buffer(1 << 14)
+            with torch.cuda.device(frames.device):
+                _lib.check(lib.vnf_mtcnn_stage_times(hd, ctypes.c_void_p(frames.data_ptr()), b, h, w, buf, len(buf),
+                                                     _lib.current_stream_ptr()))
+            seen = {}
+            for line in buf.value.decode().splitlines():
+                name, ms, nbytes = line.split()
+                e = seen.setdefault(name, [0.0, 0.0])     # chunked stages repeat: sum within one call
+                e[0] += float(ms)
+                e[1] += float(nbytes)
+            for name, (ms, nbytes) in seen.items():
+                acc.setdefault(name, {"ms": [], "bytes": nbytes})["ms"].append(ms)
+        return {k: {"ms": float(np.median(v["ms"])), "bytes": v["bytes"]} for k, v in acc.items()}
+
+    def debug_stage3(self, boxes, onet_out):
+        """O-stage decode alone (vnf_mtcnn_debug_stage3) on a caller-made single-frame candidate table: boxes (n,4)
+        before bbreg, onet_out (n,15) [prob, reg x4, landmark x x5, landmark y x5] -> (boxes (k,4), probs (k,),
+        points (k,5,2)) after threshold, bbreg, "Min" NMS and the area ordering.  Test hook for tied scores."""
+        boxes = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 4)
+        oo = np.ascontiguousarray(onet_out, dtype=np.float32).reshape(-1, 15)
+        n = boxes.shape[0]
+        hd = self._ensure(1, 64, 64)
+        fin = np.empty((max(n, 1), 15), dtype=np.float32)
+        n_out = ctypes.c_int32(0)
+        dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().vnf_mtcnn_debug_stage3(hd, boxes.ctypes.data, oo.ctypes.data, n, fin.ctypes.data,
+                                                          fin.shape[0], ctypes.byref(n_out), _lib.current_stream_ptr()))
+        fin = fin[:n_out.value]
+        return fin[:, :4].copy(), fin[:, 4].copy(), fin[:, 5:].reshape(-1, 5, 2).copy()
+
     def _require_handle(self):
         if self._handle is None:
             raise RuntimeError("results_device(): no detection has run on this detector yet")

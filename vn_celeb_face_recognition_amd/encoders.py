@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from .weights import generate_state_dict
 
-_DTYPES = {"bf16": _lib.VNF_BF16, "f16": _lib.VNF_F16, "fp16": _lib.VNF_F16, "f32": _lib.VNF_F32,
+_DTYPES = {"bf16": _lib.VNF_BF16, "f16": _lib.VNF_F16, "fp16": _lib.VNF_F16, "f16x2": _lib.VNF_F16X2, "f32": _lib.VNF_F32,
            "fp32": _lib.VNF_F32, torch.bfloat16: _lib.VNF_BF16, torch.float16: _lib.VNF_F16,
            torch.float32: _lib.VNF_F32}
 
