@@ -206,3 +206,36 @@ def test_ir100_split_f16_matches_reference_golden():
     y = m(x.cuda()).cpu().numpy()
     err = np.linalg.norm(y - g["features"], axis=1) / np.linalg.norm(g["features"], axis=1)
     assert err.max() <= 1e-4, err
+
+
+@pytest.mark.parametrize("dt,tol", [("bf16", 2.5e-2), ("f16", 3e-3)])
+def test_persistent_block17_trunk_kernel_matches_the_unfused_plan_and_the_oracle(irv1_sd, monkeypatch, dt, tol):
+    """repeat_2 (10 x Block17, inception_resnet_v1.py:70-95) runs as ONE persistent kernel on the 16-bit paths
+    (trunk17.hip: residual trunk in fp32 registers, intermediates in LDS).  Against the fp32 oracle's stage taps it
+    must be at least as close as the unfused per-convolution plan (VNF_FUSE=0), which rounds the trunk to 16 bits after
+    every block; the two plans must agree with each other to the storage precision."""
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    from oracle import irv1
+    x = seeded_normal((5, 3, 160, 160), 31)
+    taps = {}
+    ref = irv1.irv1_forward(irv1_sd, x, taps=taps).numpy()
+    fused = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=5).eval()
+    yf = fused(x.cuda()).cpu().numpy()
+    tf = {n: fused.tap(n, 5) for n in ("mixed_6a", "repeat_2", "mixed_7a")}
+    monkeypatch.setenv("VNF_FUSE", "0")
+    plain = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=5).eval()
+    yp = plain(x.cuda()).cpu().numpy()
+    tp = {n: plain.tap(n, 5) for n in ("mixed_6a", "repeat_2", "mixed_7a")}
+    assert np.array_equal(tf["mixed_6a"], tp["mixed_6a"])          # same input to the stack
+    want = taps["repeat_2"].numpy()
+    scale = np.abs(want).max()
+    ef, ep = np.abs(tf["repeat_2"] - want).max() / scale, np.abs(tp["repeat_2"] - want).max() / scale
+    rf = np.linalg.norm(tf["repeat_2"] - want) / np.linalg.norm(want)
+    rp = np.linalg.norm(tp["repeat_2"] - want) / np.linalg.norm(want)
+    print("%s repeat_2 tap vs fp32 oracle: fused max %.3e rel-L2 %.3e | unfused max %.3e rel-L2 %.3e" % (dt, ef, rf, ep, rp))
+    assert ef <= tol and rf <= tol
+    assert rf <= rp * 1.05                                          # fp32 trunk: not worse than the 16-bit trunk
+    assert np.abs(tf["repeat_2"] - tp["repeat_2"]).max() / scale <= 2 * tol
+    e_f, e_p = np.linalg.norm(yf - ref, axis=1).max(), np.linalg.norm(yp - ref, axis=1).max()
+    print("%s embedding L2 vs fp32 oracle: fused %.3e unfused %.3e" % (dt, e_f, e_p))
+    assert e_f <= max(6e-2 if dt == "bf16" else 8e-3, e_p * 1.2)

@@ -277,6 +277,7 @@ static const char* zero_page() {  // per-device 256 zero bytes for padded / out-
   if (!z[dev]) {
     if (hipMalloc((void**)&z[dev], 256) != hipSuccess) return nullptr;
     (void)hipMemset(z[dev], 0, 256);
+    (void)hipDeviceSynchronize();  // once per device: the page must be zero before any stream reads it
   }
   return z[dev];
 }

@@ -3,6 +3,7 @@
 // static plan of convolution / pooling launches on the caller's stream.
 #include "engine.h"
 #include "split_f16.h"
+#include "trunk17.h"
 
 #include <cmath>
 #include <cstdio>
@@ -169,6 +170,9 @@ int Encoder::autotune() {
     const int nn = g.chunk < part ? g.chunk : part;
     for (int oi = g.first; oi < g.last; ++oi) {
       if (ops[oi].kind != Op::CONV) continue;
+      bool in_fused = false;
+      for (const FusedStack& f : fused) in_fused |= f.active && oi >= f.first && oi < f.last;
+      if (in_fused) continue;  // replaced by a persistent kernel: nothing to tune
       ConvLayer& L = convs[ops[oi].a];
       float best = 1e30f;
       int best_cfg = -1;
@@ -251,7 +255,44 @@ int Encoder::finalize() {
   macs_alg = macs_exec = 0;
   for (auto& c : convs) { macs_alg += c.macs_alg; macs_exec += c.macs_exec; }
   if (groups.empty()) groups.push_back({0, (int)ops.size(), 1 << 30});
+  {
+    const int rc = prepare_fused();
+    if (rc != VNF_OK) return rc;
+  }
   tune_dirty = true;  // the first run() picks the tiles (after any set_streams / set_contexts of the caller)
+  return VNF_OK;
+}
+
+// Fused stacks: the per-wave weight streams are gathered on the device from the packed per-convolution weights the
+// plan already uploaded (same folding, same k order), biases are concatenated per block.
+int Encoder::prepare_fused() {
+  const int enabled = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 1;  // read at create time (tests build both plans)
+  for (FusedStack& f : fused) {
+    f.active = false;
+    if (!enabled || (dtype != BF16 && dtype != F16) || f.nblocks < 1 || f.nblocks > T17_MAX_BLOCKS) continue;
+    Trunk17Pack pk;
+    memset(&pk, 0, sizeof pk);
+    pk.nblocks = f.nblocks;
+    std::vector<float> bias((size_t)f.nblocks * T17_BIAS, 0.f);
+    static const int rows[4] = {256, 128, 128, 896}, ks[4] = {896, 896, 896, 256}, boff[4] = {0, 256, 384, 512};
+    bool ok = true;
+    for (int b = 0; b < f.nblocks && ok; ++b)
+      for (int c = 0; c < 4 && ok; ++c) {
+        const ConvLayer& L = convs[f.conv0 + 4 * b + c];
+        if (L.cout != rows[c] || L.K != ks[c] || L.Kpad != ks[c] || L.ncls != 1) { ok = false; break; }
+        pk.w[b][c] = L.w;
+        pk.kpad[c] = L.Kpad;
+        VNF_HIP(hipMemcpy(&bias[(size_t)b * T17_BIAS + boff[c]], L.bias, (size_t)rows[c] * 4, hipMemcpyDeviceToHost));
+        f.macs_alg += L.macs_alg;
+      }
+    if (!ok) return fail(VNF_E_INVALID, "fused Block17 stack: unexpected layer shapes");
+    f.wstream = dalloc(trunk17_stream_bytes(f.nblocks));
+    f.bias = (float*)upload(bias.data(), bias.size() * 4);
+    if (!f.wstream || !f.bias) return VNF_E_HIP;
+    VNF_HIP(trunk17_repack(pk, f.wstream, 0));
+    VNF_HIP(hipDeviceSynchronize());
+    f.active = true;
+  }
   return VNF_OK;
 }
 
@@ -529,6 +570,7 @@ int build_irv1(Encoder& e, WeightMap& wm) {
   e.taps["mixed_6a"] = {x17[0], 0, 896};
   // ---- repeat_2: 10 x Block17 (70-95)
   cur = 0;
+  const int r2_first_op = (int)e.ops.size(), r2_first_conv = (int)e.convs.size();
   for (int i = 0; i < 10; ++i) {
     const std::string p = "repeat_2." + std::to_string(i);
     const int X = x17[cur], Y = x17[cur == 1 ? 2 : 1];
@@ -540,6 +582,15 @@ int build_irv1(Encoder& e, WeightMap& wm) {
     cur = (cur == 1 ? 2 : 1);
   }
   e.taps["repeat_2"] = {x17[cur], 0, 896};
+  {
+    // 16-bit compute dtypes run the whole stack as one persistent kernel (trunk17.hip); the plan ops above stay as
+    // the fp32 / split-f16 path, the FLOP accounting and the source of the packed weights
+    FusedStack f;
+    f.first = r2_first_op; f.last = (int)e.ops.size();
+    f.in_buf = x17[0]; f.out_buf = x17[cur];
+    f.nblocks = 10; f.conv0 = r2_first_conv;
+    e.fused.push_back(f);
+  }
   // ---- mixed_7a (152-181)
   {
     const int X = x17[cur], O = x8[0];
@@ -863,7 +914,9 @@ int Encoder::select_ctx(hipStream_t s, int* used) {
       const size_t bytes = b.elems_per_image() * es * (size_t)max_batch;
       char* p = (char*)dalloc(bytes);
       if (!p) return VNF_E_HIP;
-      VNF_HIP(hipMemset(p, 0, bytes));
+      // on the caller's stream: ordered before this call's kernels (a null-stream hipMemset is not ordered against
+      // non-blocking streams and may land after the first layers have written their outputs)
+      VNF_HIP(hipMemsetAsync(p, 0, bytes, s));
       set.push_back(p);
     }
     float* er = (float*)dalloc((size_t)max_batch * 512 * 4);
@@ -936,6 +989,9 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
       const int nn = (i1 - n0) < step ? (i1 - n0) : step;
       for (int oi = g.first; oi < g.last; ++oi) {
         const Op& op = ops[oi];
+        const FusedStack* fs = nullptr;
+        for (const FusedStack& f : fused)
+          if (f.active && oi == f.first) fs = &f;
         if (report) {
           hipEvent_t e0;
           VNF_HIP(hipEventCreate(&e0));
@@ -943,6 +999,19 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
           prof_ev.push_back(e0);
           prof_op.push_back(oi);
           prof_n.push_back(nn);
+        }
+        if (fs) {
+          const Buf& ib = bufs[fs->in_buf];
+          const Buf& ob = bufs[fs->out_buf];
+          Trunk17Args ta;
+          ta.x = ib.ptr + (size_t)n0 * ib.elems_per_image() * es;
+          ta.y = ob.ptr + (size_t)n0 * ob.elems_per_image() * es;
+          ta.ldx = ib.C; ta.ldy = ob.C; ta.n = nn; ta.nblocks = fs->nblocks;
+          ta.wstream = fs->wstream; ta.bias = fs->bias;
+          hipError_t err = launch_trunk17(ta, dtype, s);
+          if (err != hipSuccess) return fail(VNF_E_HIP, std::string("fused Block17 stack: ") + hipGetErrorString(err));
+          oi = fs->last - 1;
+          continue;
         }
         switch (op.kind) {
           case Op::PACK: {
@@ -1019,6 +1088,17 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
     for (size_t oi = 0; oi < ops.size(); ++oi) {
       const Op& op = ops[oi];
       total += ms[oi];
+      const FusedStack* fs = nullptr;
+      for (const FusedStack& f : fused)
+        if (f.active && (int)oi >= f.first && (int)oi < f.last) fs = &f;
+      if (fs) {
+        if ((int)oi != fs->first) continue;
+        const double gf = 2.0 * fs->macs_alg * n / 1e9;
+        snprintf(line, sizeof line, "%-28s %-60s %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n", "repeat_2 (persistent trunk)",
+                 "10 x Block17 in one launch, one workgroup per image", ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
+        *report += line;
+        continue;
+      }
       if (op.kind == Op::CONV) {
         const ConvLayer& L = convs[op.a];
         const double gf = 2.0 * L.macs_alg * n / 1e9;

@@ -73,7 +73,20 @@ struct Op {
   int a = 0, b = 0, c = 0, d = 0, e = 0;  // meaning per kind (see engine.cpp)
 };
 
-struct Group { int first, last, chunk; };  // ops [first,last) run per `chunk` images (L3 residency)
+struct Group { int first, last, chunk; };
+
+// A run of plan ops that one persistent kernel replaces when the compute dtype allows it (16-bit operands):
+// ops [first, last) -- the 40 convolutions of repeat_2 -- become one launch of block17_trunk_kernel (trunk17.hip).
+struct FusedStack {
+  int first = 0, last = 0;     // op range
+  int in_buf = -1, out_buf = -1;
+  int nblocks = 0;
+  int conv0 = 0;               // index of the first of the 4*nblocks convolutions (reduce, 1x7, 7x1, up per block)
+  void* wstream = nullptr;
+  float* bias = nullptr;
+  bool active = false;
+  double macs_alg = 0;         // per image
+};  // ops [first,last) run per `chunk` images (L3 residency)
 
 struct Tap { int buf, coff, C; };
 
@@ -84,6 +97,8 @@ struct Encoder : HandleBase {
   std::vector<ConvLayer> convs;
   std::vector<Op> ops;
   std::vector<Group> groups;
+  std::vector<FusedStack> fused;
+  int prepare_fused();  // build the weight streams of the fused stacks (finalize)
   std::unordered_map<std::string, Tap> taps;
   float* emb_raw = nullptr;  // (max_batch,512) fp32 before the final normalisation
   double macs_alg = 0, macs_exec = 0;
