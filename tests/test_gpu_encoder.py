@@ -226,7 +226,7 @@ def test_persistent_block17_trunk_kernel_matches_the_unfused_plan_and_the_oracle
     plain = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=5).eval()
     yp = plain(x.cuda()).cpu().numpy()
     tp = {n: plain.tap(n, 5) for n in ("mixed_6a", "repeat_2", "mixed_7a")}
-    assert np.array_equal(tf["mixed_6a"], tp["mixed_6a"])          # same input to the stack
+    assert np.array_equal(tf["mixed_6a"], tp["mixed_6a"])          # same input to the stack (fused Block35 is bit-exact)
     want = taps["repeat_2"].numpy()
     scale = np.abs(want).max()
     ef, ep = np.abs(tf["repeat_2"] - want).max() / scale, np.abs(tp["repeat_2"] - want).max() / scale
@@ -239,3 +239,27 @@ def test_persistent_block17_trunk_kernel_matches_the_unfused_plan_and_the_oracle
     e_f, e_p = np.linalg.norm(yf - ref, axis=1).max(), np.linalg.norm(yp - ref, axis=1).max()
     print("%s embedding L2 vs fp32 oracle: fused %.3e unfused %.3e" % (dt, e_f, e_p))
     assert e_f <= max(6e-2 if dt == "bf16" else 8e-3, e_p * 1.2)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("n", [1, 7])
+def test_fused_block35_is_bitwise_the_five_launch_plan(monkeypatch, dt, n):
+    """repeat_1 (5 x Block35, inception_resnet_v1.py:36-67): one fused launch per block (block35.hip: all intermediates in
+    LDS, pixel tiles split over the waves, weights in MFMA fragment order) keeps the unfused plan's rounding points and
+    summation order, so conv2d_4b -> repeat_1 must come out bit for bit the same -- image borders (3x3 taps), the
+    padding pixels of the 19th tile and every batch position included."""
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    x = seeded_normal((n, 3, 160, 160), 57 + n).cuda()
+    monkeypatch.setenv("VNF_FUSE", "2")      # Block35 only
+    fused = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=n).eval()
+    yf = fused(x)
+    a4, r1 = fused.tap("conv2d_4b", n), fused.tap("repeat_1", n)
+    monkeypatch.setenv("VNF_FUSE", "0")
+    plain = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=n).eval()
+    yp = plain(x)
+    assert np.array_equal(a4, plain.tap("conv2d_4b", n))
+    want = plain.tap("repeat_1", n)
+    assert np.isfinite(r1).all()
+    bad = np.argwhere(r1 != want)
+    assert len(bad) == 0, (len(bad), bad[:8], r1[tuple(bad[0])], want[tuple(bad[0])])
+    assert torch.equal(yf, yp)

@@ -1,0 +1,33 @@
+// Launch interface of the fused Block35 kernel (block35.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace vnf {
+
+// weight image of one block (bytes): 48 + 3*18 + 48 fragments of 1 KiB, MFMA A-fragment order
+constexpr int B35_W1 = 0, B35_W2 = 48 * 1024, B35_W3 = 66 * 1024, B35_W4 = 84 * 1024, B35_W5 = 102 * 1024;
+constexpr int B35_FRAGS = 150;
+constexpr int B35_BIASOFF = B35_FRAGS * 1024;          // 2 KiB: the block's fp32 biases follow the weight fragments
+constexpr int B35_WIMG_BYTES = (B35_FRAGS + 2) * 1024;
+constexpr int B35_BIAS = 448;  // fp32 per block: 96 reduce | 32 branch1.1 | 32 branch2.1 | 32 branch2.2 | 256 up
+
+struct Block35Args {
+  const void* x;      // (n, 289, ldx) 16-bit NHWC block input (residual source)
+  void* y;            // (n, 289, ldy) block output
+  int ldx, ldy, n;
+  const void* wimg;   // block35_repack output of this block (weights + biases)
+  const void* zero;   // >= 16 zero bytes (padding rows of the x tiles)
+};
+
+struct Block35Pack {   // packed engine weights [rows][kpad] (k = (kh, kw, c)) of the block's five convolutions
+  const void* w[5];    // reduce (96 x 256), branch1.1, branch2.1, branch2.2 (32 x 288 each), up (256 x 96)
+  int kpad[5];
+  const float* bias;   // device [B35_BIAS]: the five convolutions' biases in that order
+};
+
+hipError_t block35_repack(const Block35Pack& p, void* out, hipStream_t s);
+hipError_t launch_block35(const Block35Args& a, int dtype, hipStream_t s);
+const char* conv_zero_page();  // conv_igemm.hip: per-device page of zero bytes
+
+}  // namespace vnf

@@ -33,6 +33,7 @@
 // (exact f32 FMA chain; the <=1e-4 parity path).
 #include <cstdlib>
 
+#include "block35.h"
 #include "conv_device.h"
 
 namespace vnf {
@@ -281,6 +282,8 @@ static const char* zero_page() {  // per-device 256 zero bytes for padded / out-
   }
   return z[dev];
 }
+
+const char* conv_zero_page() { return zero_page(); }
 
 template <typename T, int BM, int BN, int WM, int WN, int S>
 static hipError_t launch_dma(const KArgs& k, hipStream_t s) {

@@ -3,6 +3,7 @@
 // static plan of convolution / pooling launches on the caller's stream.
 #include "engine.h"
 #include "split_f16.h"
+#include "block35.h"
 #include "trunk17.h"
 
 #include <cmath>
@@ -266,10 +267,36 @@ int Encoder::finalize() {
 // Fused stacks: the per-wave weight streams are gathered on the device from the packed per-convolution weights the
 // plan already uploaded (same folding, same k order), biases are concatenated per block.
 int Encoder::prepare_fused() {
-  const int enabled = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 1;  // read at create time (tests build both plans)
+  const int enabled = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 3;  // bit 0: Block17 stack, bit 1: Block35; read at create time
   for (FusedStack& f : fused) {
     f.active = false;
     if (!enabled || (dtype != BF16 && dtype != F16) || f.nblocks < 1 || f.nblocks > T17_MAX_BLOCKS) continue;
+    if (f.kind == 35) {
+      if (!(enabled & 2)) continue;
+      std::vector<float> bias((size_t)f.nblocks * B35_BIAS, 0.f);
+      static const int rows[5] = {96, 32, 32, 32, 256}, ks[5] = {256, 288, 288, 288, 96}, boff[5] = {0, 96, 128, 160, 192};
+      f.wstream = dalloc((size_t)f.nblocks * B35_WIMG_BYTES);
+      f.bias = (float*)dalloc(bias.size() * 4);
+      if (!f.wstream || !f.bias) return VNF_E_HIP;
+      for (int b = 0; b < f.nblocks; ++b) {
+        Block35Pack pk;
+        pk.bias = f.bias + (size_t)b * B35_BIAS;
+        for (int c = 0; c < 5; ++c) {
+          const ConvLayer& L = convs[f.conv0 + 5 * b + c];
+          if (L.cout != rows[c] || L.K != ks[c] || L.ncls != 1) return fail(VNF_E_INVALID, "fused Block35: unexpected layer shapes");
+          pk.w[c] = L.w;
+          pk.kpad[c] = L.Kpad;
+          VNF_HIP(hipMemcpy(&bias[(size_t)b * B35_BIAS + boff[c]], L.bias, (size_t)rows[c] * 4, hipMemcpyDeviceToHost));
+          f.macs_alg += L.macs_alg;
+        }
+        VNF_HIP(hipMemcpy(f.bias + (size_t)b * B35_BIAS, &bias[(size_t)b * B35_BIAS], (size_t)B35_BIAS * 4, hipMemcpyHostToDevice));
+        VNF_HIP(block35_repack(pk, (char*)f.wstream + (size_t)b * B35_WIMG_BYTES, 0));
+      }
+      VNF_HIP(hipDeviceSynchronize());
+      f.active = true;
+      continue;
+    }
+    if (!(enabled & 1)) continue;
     Trunk17Pack pk;
     memset(&pk, 0, sizeof pk);
     pk.nblocks = f.nblocks;
@@ -546,6 +573,7 @@ int build_irv1(Encoder& e, WeightMap& wm) {
 
   // ---- repeat_1: 5 x Block35 (36-67)
   int cur = 0;
+  const int r1_first_op = (int)e.ops.size(), r1_first_conv = (int)e.convs.size();
   for (int i = 0; i < 5; ++i) {
     const std::string p = "repeat_1." + std::to_string(i);
     const int X = x35[cur], Y = x35[cur == 1 ? 2 : 1];
@@ -558,6 +586,13 @@ int build_irv1(Encoder& e, WeightMap& wm) {
     cur = (cur == 1 ? 2 : 1);
   }
   e.taps["repeat_1"] = {x35[cur], 0, 256};
+  {
+    FusedStack f;   // 16-bit compute dtypes: one fused launch per block (block35.hip)
+    f.kind = 35;
+    f.first = r1_first_op; f.last = (int)e.ops.size();
+    f.nblocks = 5; f.conv0 = r1_first_conv;
+    e.fused.push_back(f);
+  }
   // ---- mixed_6a (129-149)
   {
     const int X = x35[cur], O = x17[0];
@@ -1000,6 +1035,23 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
           prof_op.push_back(oi);
           prof_n.push_back(nn);
         }
+        if (fs && fs->kind == 35) {
+          for (int b = 0; b < fs->nblocks; ++b) {
+            const ConvLayer& up = convs[fs->conv0 + 5 * b + 4];   // residual source = block input, segment 0 = block output
+            const Buf& ib = bufs[up.res_buf];
+            const Buf& ob = bufs[up.seg[0].buf];
+            Block35Args ba;
+            ba.x = ib.ptr + (size_t)n0 * ib.elems_per_image() * es;
+            ba.y = ob.ptr + (size_t)n0 * ob.elems_per_image() * es;
+            ba.ldx = ib.C; ba.ldy = ob.C; ba.n = nn;
+            ba.wimg = (const char*)fs->wstream + (size_t)b * B35_WIMG_BYTES;
+            ba.zero = conv_zero_page();
+            hipError_t err = launch_block35(ba, dtype, s);
+            if (err != hipSuccess) return fail(VNF_E_HIP, std::string("fused Block35: ") + hipGetErrorString(err));
+          }
+          oi = fs->last - 1;
+          continue;
+        }
         if (fs) {
           const Buf& ib = bufs[fs->in_buf];
           const Buf& ob = bufs[fs->out_buf];
@@ -1094,8 +1146,11 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
       if (fs) {
         if ((int)oi != fs->first) continue;
         const double gf = 2.0 * fs->macs_alg * n / 1e9;
-        snprintf(line, sizeof line, "%-28s %-60s %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n", "repeat_2 (persistent trunk)",
-                 "10 x Block17 in one launch, one workgroup per image", ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
+        snprintf(line, sizeof line, "%-28s %-60s %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n",
+                 fs->kind == 35 ? "repeat_1 (fused blocks)" : "repeat_2 (persistent trunk)",
+                 fs->kind == 35 ? "5 x Block35, one launch per block, one workgroup per image"
+                                : "10 x Block17 in one launch, one workgroup per image",
+                 ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
         *report += line;
         continue;
       }

@@ -75,9 +75,11 @@ struct Op {
 
 struct Group { int first, last, chunk; };
 
-// A run of plan ops that one persistent kernel replaces when the compute dtype allows it (16-bit operands):
-// ops [first, last) -- the 40 convolutions of repeat_2 -- become one launch of block17_trunk_kernel (trunk17.hip).
+// A run of plan ops that fused kernels replace when the compute dtype allows it (16-bit operands): the 40 convolutions
+// of repeat_2 become one launch of block17_trunk_kernel (trunk17.hip), the 25 of repeat_1 five launches of
+// block35_kernel (block35.hip).
 struct FusedStack {
+  int kind = 17;               // 17: persistent Block17 stack (trunk17.hip); 35: one fused launch per Block35 (block35.hip)
   int first = 0, last = 0;     // op range
   int in_buf = -1, out_buf = -1;
   int nblocks = 0;
