@@ -30,7 +30,8 @@ def main(args, pipe, threshold, frame_idxes):
     with open(args.output_tracker, 'w') as f:
         f.write('')
     append_log_to_file(args.output_tracker, tracker_header(args.track_bbox))
-    frames_iter, fps = open_frame_source(args.video_path)
+    frames_iter = open_frame_source(args.video_path)
+    fps = frames_iter.fps
     if args.fps_video > 0:
         fps = args.fps_video
     count = processed_frame = 0

@@ -129,6 +129,105 @@ def test_all_gather_embeddings_world_size_2_gloo():
     assert res == [(0, True, 0, 10), (1, True, 10, 20)]
 
 
+class _StubTicket:
+    def __init__(self, counts, boxes, emb):
+        self._r = (counts, boxes, emb, None, None)
+
+    def result(self):
+        return self._r
+
+
+class _StubPipe:
+    """FacePipeline stand-in on the CPU: frame i (every pixel == i % 251) "contains" i % 3 faces whose embedding's first
+    component is the frame number and whose box encodes (frame, face); the classifier returns that number as the class."""
+    label2name = {"label": list(range(1000)), "name": ["n%d" % i for i in range(1000)]}
+    threshold = 0.5
+
+    class detector:
+        @staticmethod
+        def _to_device_frames(q):
+            return torch.from_numpy(np.stack(q)), False
+
+    class classifier:
+        num_classes = 1000
+
+        @staticmethod
+        def classify(emb, want_logp=False):
+            return None, emb[:, 0].to(torch.int32), torch.ones(emb.shape[0])
+
+    def __init__(self):
+        self.submitted = []
+
+    def submit(self, frames_dev, classify=True):
+        assert classify is False
+        ids = [int(f[0, 0, 1]) * 251 + int(f[0, 0, 0]) for f in frames_dev]      # frame number stored in two channels
+        self.submitted.append(ids)
+        counts = [i % 3 for i in ids]
+        n = sum(counts)
+        emb = torch.zeros((n, 512))
+        boxes = np.zeros((n, 4), np.float32)
+        o = 0
+        for i, c in zip(ids, counts):
+            for k in range(c):
+                emb[o, 0] = i
+                boxes[o] = [i, k, i + 10, k + 20]
+                o += 1
+        return _StubTicket(counts, boxes, emb)
+
+    def flush(self):
+        pass
+
+
+def _stream_worker(rank, world, port, q, n_total, n_frames):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from vn_celeb_face_recognition_amd import dist as vdist
+    from vn_celeb_face_recognition_amd.video import FrameSource, run_stream
+    vdist.init_from_env("gloo")
+    frames = np.zeros((n_total, 4, 6, 3), np.uint8)
+    for i in range(n_total):
+        frames[i, :, :, 0], frames[i, :, :, 1] = (i + 1) % 251, (i + 1) // 251
+    src = FrameSource(frames, 25.0)
+    pipe = _StubPipe()
+    rows, processed = run_stream(src, pipe, n_frames, rank, world, device="cpu")
+    q.put((rank, processed, src.reads, pipe.submitted, "".join(rows[k] for k in sorted(rows)) if rank == 0 else ""))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_video_stream_control_flow_two_ranks_gloo():
+    """demo_video's multi-rank path (video.run_stream): every rank submits only its own batches to the throughput
+    pipeline, the per-round all-gather carries embeddings + boxes, rank 0 classifies and emits every frame's tracker
+    row in frame order -- compared with the single-process run of the same stream."""
+    import torch.multiprocessing as mp
+    from vn_celeb_face_recognition_amd.video import FrameSource, run_stream
+    n_total, n_frames = 23, 4                      # 6 batches: rank 0 gets 0,2,4 -- rank 1 gets 1,3,5 (the short one)
+    frames = np.zeros((n_total, 4, 6, 3), np.uint8)
+    for i in range(n_total):
+        frames[i, :, :, 0], frames[i, :, :, 1] = (i + 1) % 251, (i + 1) // 251
+    rows1, p1 = run_stream(FrameSource(frames, 25.0), _StubPipe(), n_frames, 0, 1, device="cpu")
+    want = "".join(rows1[k] for k in sorted(rows1))
+    assert p1 == n_total and sorted(rows1) == list(range(1, n_total + 1))
+    assert rows1[5] == '0.2,"[\'n5\', \'n5\']",5,"[[%s, 0.0, %s, 5.0], [%s, 0.25, %s, 5.25]]"\n' % (5 / 6, 15 / 6, 5 / 6, 15 / 6)
+    assert rows1[3] == '0.12,"[]",3,"[]"\n'
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_stream_worker, args=(r, 2, port, q, n_total, n_frames)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    (r0, p0, reads0, sub0, text0), (r1, pr1, reads1, sub1, _) = res
+    assert (p0, pr1) == (12, 11) and (reads0, reads1) == (12, 11)            # each rank read only its own frames
+    assert sub0 == [[1, 2, 3, 4], [9, 10, 11, 12], [17, 18, 19, 20]]
+    assert sub1 == [[5, 6, 7, 8], [13, 14, 15, 16], [21, 22, 23]]
+    assert text0 == want
+
+
 def test_cli_helpers(tmp_path):
     sys.path.insert(0, REPO)
     import find_embedding as fe

@@ -59,18 +59,18 @@ def draw_boxes_on_image(rgb_image, boxes, list_names):
 
 
 def open_frame_source(path):
-    """Iterator over RGB frames + nominal fps.  Accepts a directory of images (sorted), a .npy/.npz
-    array of (T,H,W,3) uint8 frames, or a video file when OpenCV is importable (demo_video.py:78-81)."""
+    """video.FrameSource over RGB frames.  Accepts a directory of images (sorted; random access: a rank decodes only its
+    own batches), a .npy/.npz array of (T,H,W,3) uint8 frames (memory-mapped), or a video file when OpenCV is
+    importable (demo_video.py:78-81; sequential: the other ranks' frames are decoded and dropped)."""
     import os
+    from .video import FrameSource
     if os.path.isdir(path):
         files = sorted(f for f in os.listdir(path) if f.lower().endswith(('.png', '.jpg', '.jpeg', '.bmp')))
-        return (read_rgb(os.path.join(path, f)) for f in files), 25.0
+        return FrameSource([os.path.join(path, f) for f in files], 25.0, load=read_rgb)
     if path.endswith('.npy'):
-        arr = np.load(path, mmap_mode='r')
-        return (np.asarray(a) for a in arr), 30.0
+        return FrameSource(np.load(path, mmap_mode='r'), 30.0)
     if path.endswith('.npz'):
-        arr = np.load(path)['arr_0']
-        return (a for a in arr), 30.0
+        return FrameSource(np.load(path)['arr_0'], 30.0)
     try:
         import cv2
     except ImportError:
@@ -86,4 +86,4 @@ def open_frame_source(path):
                 break
             yield frame[:, :, ::-1]
         cap.release()
-    return gen(), fps
+    return FrameSource(gen(), fps)
