@@ -117,6 +117,27 @@ int vnf_mlp_create(const vnf_tensor_desc* weights, int n_weights, int input_dim,
 int vnf_classify(vnf_handle h, const float* emb, int f, float* logp_out, int32_t* argmax_out,
                  float* prob_out, void* stream);
 
+/* classifier training --------------------------------------------------- */
+/* One optimisation step of trainer/classification_trainer.py:13-21 for models/mlp_model.py with
+ * torch.optim.Adam semantics (coupled weight decay, no amsgrad): weights = the four MLPModel state_dict
+ * tensors (initial values), fp32 end to end.  The handle owns parameters, gradients and Adam moments. */
+int vnf_mlp_trainer_create(const vnf_tensor_desc* weights, int n_weights, int input_dim, int num_classes,
+                           int max_batch, float beta1, float beta2, float eps, float weight_decay,
+                           vnf_handle* out);
+/* emb: device (b,input_dim) fp32; target: device (b,) int64; dropout_mask: device (b,2048) fp32 holding
+ * F.dropout's factor per hidden unit (0 or 1/(1-p); NULL = no dropout; ignored when train == 0).
+ * train != 0: forward, NLL loss, backward, Adam step with learning rate lr; train == 0: forward + loss only
+ * (classification_trainer.py:48-56).  loss_out: device fp32 scalar (mean NLL of the batch); hits_out: device
+ * int32 scalar (argmax == target count, losses/metrics.py:3-7).  Enqueued on `stream`, no synchronisation. */
+int vnf_mlp_train_step(vnf_handle h, const float* emb, const int64_t* target, int b,
+                       const float* dropout_mask, float lr, int train, float* loss_out,
+                       int32_t* hits_out, void* stream);
+/* checkpoint access (trainer/base_trainer.py:83-105): name = a state_dict key, kind 0 = parameter,
+ * 1 = Adam exp_avg, 2 = Adam exp_avg_sq; host fp32 arrays of exactly numel elements.  Synchronise. */
+int vnf_mlp_trainer_get(vnf_handle h, const char* name, int kind, float* host_out, int64_t numel);
+int vnf_mlp_trainer_set(vnf_handle h, const char* name, int kind, const float* host_in, int64_t numel);
+int vnf_mlp_trainer_step_count(vnf_handle h, int64_t* step_io, int set);  /* Adam's step counter */
+
 /* detector --------------------------------------------------------------------------------- */
 typedef struct {
   int32_t min_face_size;   /* mtcnn.py:201 */

@@ -277,6 +277,132 @@ def golden_celeb_stat():
     print("celeb_stat:", {k: len(v.get("text", "")) if isinstance(v, dict) and "text" in v else len(v) for k, v in out.items()})
 
 
+def mlp_train_case():
+    """The synthetic task shared by the golden generator and tests/test_gpu_train.py: 12 identities, unit embeddings =
+    class centre + noise; written as the reference's own on-disk formats (<stem>.npz with arr_0, label json of
+    class -> file names: find_embedding.py:38-41, data_loader/vn_celeb_dataset.py:39-47)."""
+    rng = np.random.default_rng(11)
+    n_cls, per_cls_train, per_cls_val = 12, 13, 4
+    centres = rng.normal(size=(n_cls, 512)).astype(np.float32)
+    files, train, val = {}, {}, {}
+    for c in range(n_cls):
+        for k in range(per_cls_train + per_cls_val):
+            e = centres[c] + 1.6 * rng.normal(size=512).astype(np.float32)
+            e = (e / np.linalg.norm(e)).astype(np.float32)
+            name = "c%02d_%02d.png" % (c, k)
+            files[name] = e
+            (train if k < per_cls_train else val).setdefault(str(c), []).append(name)
+    cfg = {
+        "name": "mlp_train golden", "data_path": "data",
+        "train_dataset": {"name": "VNCelebEmbDataset", "args": {"data_dir": "emb", "label_file": "train.json"}},
+        "train_data_loader": {"name": "train", "args": {"batch_size": 64, "shuffle": True, "num_workers": 0}},
+        "val_dataset": {"name": "VNCelebEmbDataset", "args": {"data_dir": "emb", "label_file": "val.json"}},
+        "val_data_loader": {"name": "val", "args": {"batch_size": 32, "shuffle": False, "num_workers": 0}},
+        "transforms": "none", "metrics": ["accuracy"], "loss": "neg_log_llhood",
+        "model": {"name": "MLPModel", "args": {"input_dim": 512, "num_classes": n_cls}},
+        "trainer": {"name": "ClassificationTrainer", "resume_path": "", "save_dir": "saved", "device": "CPU", "log_step": 30,
+                    "do_validation": True, "validation_step": 1, "epochs": 6, "tracked_metric": ["val_neg_log_llhood", "min"],
+                    "patience": 10, "save_period": 3, "save_result": False, "track4plot": True},
+        "optimizer": {"name": "Adam", "args": {"lr": 0.002, "weight_decay": 1e-04}},
+        "lr_scheduler": {"name": "ReduceLROnPlateau", "args": {"mode": "min", "threshold": 0.5, "factor": 0.5, "patience": 1,
+                                                               "min_lr": 1e-05, "threshold_mode": "rel"}},
+    }
+    return files, train, val, cfg
+
+
+def write_mlp_train_case(root):
+    files, train, val, cfg = mlp_train_case()
+    os.makedirs(os.path.join(root, "emb"), exist_ok=True)
+    for name, e in files.items():
+        np.savez_compressed(os.path.join(root, "emb", name.split(".")[0] + ".npz"), e)
+    for fn, d in (("train.json", train), ("val.json", val)):
+        with open(os.path.join(root, fn), "w") as f:
+            json.dump(d, f)
+    cfg = json.loads(json.dumps(cfg))
+    for k in ("train_dataset", "val_dataset"):
+        cfg[k]["args"]["data_dir"] = os.path.join(root, "emb")
+        cfg[k]["args"]["label_file"] = os.path.join(root, cfg[k]["args"]["label_file"])
+    cfg["trainer"]["save_dir"] = os.path.join(root, "saved")
+    return cfg
+
+
+def golden_mlp_train():
+    """MLP training on embeddings by the reference's OWN trainer: trainer/base_trainer.py +
+    trainer/classification_trainer.py, data_loader/vn_celeb_emb_dataset.py, losses, models/mlp_model.py, driven exactly
+    as train.py:22-76 drives them (seed 123, Adam, ReduceLROnPlateau, DataLoader shuffle, dropout), on CPU."""
+    import tempfile
+    import torch.optim as otpm
+    from torch.utils.data import DataLoader
+    for name in ("matplotlib", "matplotlib.pyplot", "imgaug", "imgaug.augmenters"):      # imported, never used on this path
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torchvision"].transforms.Compose = lambda *a, **k: None
+    sys.modules["torchvision"].transforms.Lambda = lambda *a, **k: None
+    sys.modules["torchvision"].transforms.ToTensor = lambda *a, **k: None
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    root = tempfile.mkdtemp(prefix="vnf_mlp_train_")
+    cfg = write_mlp_train_case(root)
+    os.chdir(root)                                    # the reference trainer logs relative to the working directory
+    try:
+        for pkg in ("trainer", "data_loader"):            # bypass the package __init__ files (they import torchvision models / imgaug pipelines)
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(REF, pkg)]
+            sys.modules[pkg] = m
+        import losses as loss_md
+        cls_tr = importlib.import_module("trainer.classification_trainer").ClassificationTrainer
+        ds_cls = importlib.import_module("data_loader.vn_celeb_emb_dataset").VNCelebEmbDataset
+        torch.manual_seed(123)                           # train.py:16-20
+        np.random.seed(123)
+        train_ds = ds_cls(**cfg["train_dataset"]["args"], transforms=None)
+        train_loader = DataLoader(dataset=train_ds, **cfg["train_data_loader"]["args"])
+        val_ds = ds_cls(**cfg["val_dataset"]["args"], transforms=None)
+        val_loader = DataLoader(dataset=val_ds, **cfg["val_data_loader"]["args"])
+        model = ref("mlp_model").MLPModel(**cfg["model"]["args"])
+        init = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+        criterion = getattr(loss_md, cfg["loss"])
+        metrics = [getattr(loss_md, x) for x in cfg["metrics"]]
+        optimizer = getattr(otpm, cfg["optimizer"]["name"])(model.parameters(), **cfg["optimizer"]["args"])
+        sched = getattr(otpm.lr_scheduler, cfg["lr_scheduler"]["name"])(optimizer, **cfg["lr_scheduler"]["args"])
+        tr = cls_tr(cfg, model, criterion, metrics, optimizer, sched)
+        tr.setup_loader(train_loader, val_loader)
+        # the per-epoch learning rate is not logged by the reference: wrap its epoch method to record it
+        lrs, logs = [], []
+        orig = tr._train_epoch
+
+        def wrapped(epoch):
+            r = orig(epoch)
+            lrs.append(optimizer.param_groups[0]["lr"])
+            logs.append({k: float(v) for k, v in r.items()})
+            return r
+        tr._train_epoch = wrapped
+        tr.train(cfg["trainer"]["track4plot"])
+        ck_dir = str(tr.save_dir)
+        cks = sorted(os.listdir(ck_dir))
+        cp = torch.load(os.path.join(ck_dir, "checkpoint-epoch6.pth"), weights_only=False)   # our own fresh file
+        sd = {k: v.numpy() for k, v in cp["state_dict"].items()}
+        track = open(os.path.join(str(tr.log_dir), "log_loss.txt")).read()
+    finally:
+        os.chdir(cwd)
+    out = {
+        "init_dense_1_weight_sample": init["dense_1.weight"].reshape(-1)[::4099], "init_dense_2_bias": init["dense_2.bias"],
+        "final_dense_1_weight_sample": sd["dense_1.weight"].reshape(-1)[::4099], "final_dense_1_bias": sd["dense_1.bias"],
+        "final_dense_2_weight_sample": sd["dense_2.weight"].reshape(-1)[::97], "final_dense_2_bias": sd["dense_2.bias"],
+        "lr_after_epoch": np.array(lrs), "train_loss": np.array([l["neg_log_llhood"] for l in logs]),
+        "train_acc": np.array([l["accuracy"] for l in logs]), "val_loss": np.array([l["val_neg_log_llhood"] for l in logs]),
+        "val_acc": np.array([l["val_accuracy"] for l in logs]),
+        "exp_avg_sq_dense_2_bias": cp["optimizer"]["state"][3]["exp_avg_sq"].numpy(),
+        "adam_step": np.array(float(cp["optimizer"]["state"][0]["step"])),
+    }
+    np.savez_compressed(os.path.join(OUT, "mlp_train_ref.npz"), **out)
+    meta = {"checkpoint_files": cks, "checkpoint_keys": sorted(cp.keys()), "arch": cp["arch"], "epoch": cp["epoch"],
+            "monitor_best": float(cp["monitor_best"]), "optimizer_state_keys": sorted(cp["optimizer"]["state"][0].keys()),
+            "param_group_keys": sorted(cp["optimizer"]["param_groups"][0].keys()), "log_loss_txt": track}
+    with open(os.path.join(OUT, "mlp_train_ref.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    shutil.rmtree(root, ignore_errors=True)
+    print("mlp_train:", out["train_loss"], out["val_loss"], out["lr_after_epoch"], cks)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_shim()

@@ -46,6 +46,12 @@ SIGNATURES = {
     "vnf_encoder_set_contexts": (_I, [_P, _I]),
     "vnf_mlp_create": (_I, [ctypes.POINTER(TensorDesc), _I, _I, _I, _I, ctypes.POINTER(_P)]),
     "vnf_classify": (_I, [_P, _P, _I, _P, _P, _P, _P]),
+    "vnf_mlp_trainer_create": (_I, [ctypes.POINTER(TensorDesc), _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                   ctypes.c_float, ctypes.POINTER(_P)]),
+    "vnf_mlp_train_step": (_I, [_P, _P, _P, _I, _P, ctypes.c_float, _I, _P, _P, _P]),
+    "vnf_mlp_trainer_get": (_I, [_P, ctypes.c_char_p, _I, _P, ctypes.c_int64]),
+    "vnf_mlp_trainer_set": (_I, [_P, ctypes.c_char_p, _I, _P, ctypes.c_int64]),
+    "vnf_mlp_trainer_step_count": (_I, [_P, ctypes.POINTER(ctypes.c_int64), _I]),
     "vnf_mtcnn_create": (_I, [ctypes.POINTER(TensorDesc), _I, ctypes.POINTER(TensorDesc), _I,
                               ctypes.POINTER(TensorDesc), _I, ctypes.POINTER(MtcnnCfg), ctypes.POINTER(_P)]),
     "vnf_mtcnn_detect": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, ctypes.POINTER(ctypes.c_int32), _P]),
