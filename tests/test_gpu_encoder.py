@@ -263,3 +263,28 @@ def test_fused_block35_is_bitwise_the_five_launch_plan(monkeypatch, dt, n):
     bad = np.argwhere(r1 != want)
     assert len(bad) == 0, (len(bad), bad[:8], r1[tuple(bad[0])], want[tuple(bad[0])])
     assert torch.equal(yf, yp)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("n", [1, 3, 130])
+def test_fused_stem_2a_2b_maxpool_is_bitwise_the_three_launch_plan(monkeypatch, dt, n):
+    """conv2d_2a -> conv2d_2b -> maxpool_3a (inception_resnet_v1.py:282-285) as one rolling-row launch (stem_mid.hip)
+    keeps the unfused plan's rounding points and summation order: the pooled map and everything after it must be bit
+    for bit the three-launch plan's -- first / last rows and columns (2b's zero padding, the valid-conv edge of 2a),
+    the 128-image sub-batch boundary of the stem group (n = 130) included."""
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    x = seeded_normal((n, 3, 160, 160), 91 + n).cuda()
+    monkeypatch.setenv("VNF_FUSE", "4")      # the stem kernel only
+    fused = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=n).eval()
+    yf = fused(x)
+    k = min(n, 4)
+    pf = fused.tap("maxpool_3a", n)
+    monkeypatch.setenv("VNF_FUSE", "0")
+    plain = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=n).eval()
+    yp = plain(x)
+    want = plain.tap("maxpool_3a", n)
+    assert np.isfinite(pf).all()
+    bad = np.argwhere(pf != want)
+    assert len(bad) == 0, (len(bad), bad[:8], pf[tuple(bad[0])], want[tuple(bad[0])])
+    assert np.array_equal(fused.tap("conv2d_4b", k), plain.tap("conv2d_4b", k))
+    assert torch.equal(yf, yp)

@@ -4,6 +4,7 @@
 #include "engine.h"
 #include "split_f16.h"
 #include "block35.h"
+#include "stem_mid.h"
 #include "trunk17.h"
 
 #include <cmath>
@@ -267,10 +268,30 @@ int Encoder::finalize() {
 // Fused stacks: the per-wave weight streams are gathered on the device from the packed per-convolution weights the
 // plan already uploaded (same folding, same k order), biases are concatenated per block.
 int Encoder::prepare_fused() {
-  const int enabled = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 3;  // bit 0: Block17 stack, bit 1: Block35; read at create time
+  const int enabled = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 7;  // bit 0: Block17 stack, bit 1: Block35, bit 2: stem 2a+2b+pool; read at create time
   for (FusedStack& f : fused) {
     f.active = false;
     if (!enabled || (dtype != BF16 && dtype != F16) || f.nblocks < 1 || f.nblocks > T17_MAX_BLOCKS) continue;
+    if (f.kind == 2) {
+      if (!(enabled & 4)) continue;
+      const ConvLayer& c2a = convs[f.conv0];
+      const ConvLayer& c2b = convs[f.conv0 + 1];
+      if (c2a.cout != 32 || c2a.K != 288 || c2b.cout != 64 || c2b.K != 288 || c2a.ncls != 1 || c2b.ncls != 1)
+        return fail(VNF_E_INVALID, "fused stem: unexpected layer shapes");
+      StemMidPack pk;
+      pk.w[0] = c2a.w; pk.kpad[0] = c2a.Kpad;
+      pk.w[1] = c2b.w; pk.kpad[1] = c2b.Kpad;
+      f.wstream = dalloc(SM_WFRAG_BYTES);
+      f.bias = (float*)dalloc(SM_BIAS * 4);
+      if (!f.wstream || !f.bias) return VNF_E_HIP;
+      VNF_HIP(hipMemcpy(f.bias, c2a.bias, 32 * 4, hipMemcpyDeviceToDevice));
+      VNF_HIP(hipMemcpy(f.bias + 32, c2b.bias, 64 * 4, hipMemcpyDeviceToDevice));
+      VNF_HIP(stem_mid_repack(pk, f.wstream, 0));
+      VNF_HIP(hipDeviceSynchronize());
+      f.macs_alg = c2a.macs_alg + c2b.macs_alg;
+      f.active = true;
+      continue;
+    }
     if (f.kind == 35) {
       if (!(enabled & 2)) continue;
       std::vector<float> bias((size_t)f.nblocks * B35_BIAS, 0.f);
@@ -560,9 +581,17 @@ int build_irv1(Encoder& e, WeightMap& wm) {
       e.ops.push_back(op);
     }
   }
-  TRY(simple("conv2d_2a", b_1a, 0, 32, 32, 32, 3, 3, 1, 0, 0, b_2a, 0));
-  TRY(simple("conv2d_2b", b_2a, 0, 32, 32, 64, 3, 3, 1, 1, 1, b_2b, 0));
-  add_maxpool(e, b_2b, b_3a, 0);
+  {
+    FusedStack f;   // 16-bit compute dtypes: conv2d_2a + conv2d_2b + maxpool_3a as one rolling-row launch (stem_mid.hip)
+    f.kind = 2;
+    f.first = (int)e.ops.size(); f.conv0 = (int)e.convs.size();
+    f.in_buf = b_1a; f.out_buf = b_3a; f.nblocks = 1;
+    TRY(simple("conv2d_2a", b_1a, 0, 32, 32, 32, 3, 3, 1, 0, 0, b_2a, 0));
+    TRY(simple("conv2d_2b", b_2a, 0, 32, 32, 64, 3, 3, 1, 1, 1, b_2b, 0));
+    add_maxpool(e, b_2b, b_3a, 0);
+    f.last = (int)e.ops.size();
+    e.fused.push_back(f);
+  }
   TRY(simple("conv2d_3b", b_3a, 0, 64, 64, 80, 1, 1, 1, 0, 0, b_3b, 0));
   TRY(simple("conv2d_4a", b_3b, 0, 80, 80, 192, 3, 3, 1, 0, 0, b_4a, 0));
   TRY(simple("conv2d_4b", b_4a, 0, 192, 192, 256, 3, 3, 2, 0, 0, x35[0], 0));
@@ -668,7 +697,11 @@ int build_irv1(Encoder& e, WeightMap& wm) {
   }
   { Op op; op.kind = Op::L2NORM; e.ops.push_back(op); }
 
-  int chunk = 128;
+  // unfused, the stem runs in sub-batches of 128 images so its big producer -> consumer tensors stay inside the
+  // Infinity Cache; with conv2d_2a/2b/maxpool fused (one workgroup per image, no big intermediate) a sub-batch would
+  // only leave half the CUs without a workgroup
+  const int fuse_mask = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 7;
+  int chunk = ((fuse_mask & 4) && (e.dtype == BF16 || e.dtype == F16)) ? 256 : 128;
   if (const char* c = getenv("VNF_STEM_CHUNK")) chunk = atoi(c) > 0 ? atoi(c) : chunk;
   e.groups.push_back({0, stem_end, chunk});
   e.groups.push_back({stem_end, (int)e.ops.size(), 1 << 30});
@@ -1035,6 +1068,19 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
           prof_op.push_back(oi);
           prof_n.push_back(nn);
         }
+        if (fs && fs->kind == 2) {
+          const Buf& ib = bufs[fs->in_buf];
+          const Buf& ob = bufs[fs->out_buf];
+          StemMidArgs sa;
+          sa.x = ib.ptr + (size_t)n0 * ib.elems_per_image() * es;
+          sa.y = ob.ptr + (size_t)n0 * ob.elems_per_image() * es;
+          sa.ldx = ib.C; sa.ldy = ob.C; sa.n = nn;
+          sa.wfrag = fs->wstream; sa.bias = fs->bias;
+          hipError_t err = launch_stem_mid(sa, dtype, s);
+          if (err != hipSuccess) return fail(VNF_E_HIP, std::string("fused stem: ") + hipGetErrorString(err));
+          oi = fs->last - 1;
+          continue;
+        }
         if (fs && fs->kind == 35) {
           for (int b = 0; b < fs->nblocks; ++b) {
             const ConvLayer& up = convs[fs->conv0 + 5 * b + 4];   // residual source = block input, segment 0 = block output
@@ -1147,9 +1193,10 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
         if ((int)oi != fs->first) continue;
         const double gf = 2.0 * fs->macs_alg * n / 1e9;
         snprintf(line, sizeof line, "%-28s %-60s %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n",
-                 fs->kind == 35 ? "repeat_1 (fused blocks)" : "repeat_2 (persistent trunk)",
+                 fs->kind == 35 ? "repeat_1 (fused blocks)" : fs->kind == 2 ? "conv2d_2a+2b+maxpool_3a" : "repeat_2 (persistent trunk)",
                  fs->kind == 35 ? "5 x Block35, one launch per block, one workgroup per image"
-                                : "10 x Block17 in one launch, one workgroup per image",
+                 : fs->kind == 2 ? "rolling rows, one launch, one workgroup per image"
+                                 : "10 x Block17 in one launch, one workgroup per image",
                  ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
         *report += line;
         continue;

@@ -79,7 +79,8 @@ struct Group { int first, last, chunk; };
 // of repeat_2 become one launch of block17_trunk_kernel (trunk17.hip), the 25 of repeat_1 five launches of
 // block35_kernel (block35.hip).
 struct FusedStack {
-  int kind = 17;               // 17: persistent Block17 stack (trunk17.hip); 35: one fused launch per Block35 (block35.hip)
+  int kind = 17;               // 17: persistent Block17 stack (trunk17.hip); 35: one fused launch per Block35 (block35.hip);
+                               // 2: conv2d_2a + conv2d_2b + maxpool_3a in one launch (stem_mid.hip)
   int first = 0, last = 0;     // op range
   int in_buf = -1, out_buf = -1;
   int nblocks = 0;

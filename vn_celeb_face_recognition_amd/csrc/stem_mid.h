@@ -1,0 +1,27 @@
+// Launch interface of the fused conv2d_2a -> conv2d_2b -> maxpool_3a kernel (stem_mid.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace vnf {
+
+constexpr int SM_WFRAG_BYTES = 54 * 1024;   // 6 channel tiles x 9 taps of 1-KiB MFMA A-fragments
+constexpr int SM_BIAS = 96;                 // fp32: 32 (conv2d_2a) | 64 (conv2d_2b)
+
+struct StemMidArgs {
+  const void* x;       // (n, 79, 79, ldx) 16-bit NHWC conv2d_1a output (32 channels used)
+  void* y;             // (n, 38, 38, ldy) pooled output, 64 channels
+  int ldx, ldy, n;
+  const void* wfrag;   // stem_mid_repack output
+  const float* bias;   // [SM_BIAS]
+};
+
+struct StemMidPack {    // packed engine weights [rows][kpad], k = (kh, kw, c): conv2d_2a (32 x 288), conv2d_2b (64 x 288)
+  const void* w[2];
+  int kpad[2];
+};
+
+hipError_t stem_mid_repack(const StemMidPack& p, void* out, hipStream_t s);
+hipError_t launch_stem_mid(const StemMidArgs& a, int dtype, hipStream_t s);
+
+}  // namespace vnf

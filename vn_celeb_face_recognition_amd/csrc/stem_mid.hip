@@ -1,0 +1,288 @@
+// conv2d_2a -> conv2d_2b -> maxpool_3a of the InceptionResnetV1 stem (/root/reference/models/inception_resnet_v1.py:
+// 221-224, 282-285) as ONE launch: one workgroup (8 waves) per image walks the image top to bottom, one row per step,
+// with every intermediate row in LDS.
+//
+//   conv2d_1a output (79x79x32, NHWC, from stem_conv1a_kernel)
+//     -> 2a: 3x3 valid, 32->32, BN+ReLU  (77x77x32)
+//     -> 2b: 3x3 pad 1,  32->64, BN+ReLU (77x77x64)
+//     -> maxpool 3x3 stride 2            (38x38x64)  -> global
+//
+// Unfused these three are HBM/L2-bound launches moving 0.73 GB per 256 images (2a: 102 MB in + 97 MB out, 2b: 97 MB
+// in + 194 MB out, pool: 194 MB in + 47 MB out) at 250-330 TFLOP/s; fused, the only traffic is the 102 MB in and the
+// 47 MB out, and the bound is the MFMA pipe (84 GFLOP per 256 images).
+//
+// Software pipeline over rows, one workgroup barrier per step s:
+//   DMA    : 1a row s+8 -> input ring (12 rows)                             (LDS-DMA, 5 x 1 KiB pieces per row; the rows come
+//            from HBM, a round trip is several steps long: 8 rows of run-ahead, counted wait 5 steps behind the issue)
+//   2a     : output row s     from input rows s..s+2       -> A2 ring (4 rows, stored with one zero pixel either side)
+//   2b     : output row s-2   from A2 rows s-3..s-1        -> B2 ring (6 rows)   (rows -1 and 77 are a zero row)
+//   pool   : output row (s-5)/2 on odd s from B2 rows s-5..s-3 -> global, 16-byte stores
+// Wave roles (weights live in REGISTERS, 9 MFMA A-fragments per 16-channel tile, loaded once):
+//   waves 0-3: 2b, channel tile = wave, all 5 pixel tiles of the row   (45 MFMAs per step)
+//   waves 4-7: 2a, channel tile = wave & 1, pixel tiles {0,1,2} (waves 4,5) or {3,4} (waves 6,7); they also pool
+//              (packed 16-bit integer max: the rows are ReLU outputs); waves 6,7 issue the DMA
+// Rounding points and summation order are those of the unfused plan (16-bit rows after each conv, fp32 accumulate over
+// (kh,kw,c) in order, bias added after the sum), so the result is bit-identical to it.
+#include <type_traits>
+
+#include "conv_device.h"
+#include "stem_mid.h"
+
+namespace vnf {
+
+namespace {
+
+constexpr int W1A = 79, W2 = 77, WP = 38;
+constexpr int IN_ROW = 84 * 64;        // 1a row: 79 px x 32 ch (64 B), padded to 84 px so tile 4's taps stay inside
+constexpr int A2_ROW = 84 * 64;        // 2a row: col 0 and col 78 are zero padding of 2b, pixels at 1..77
+constexpr int B2_ROW = 80 * 128;       // 2b row: 77 px x 64 ch (128 B), 5 pixel tiles
+constexpr int IN_RING = 12, A2_RING = 4, B2_RING = 6;
+constexpr int AHEAD = 8;               // rows the input DMA runs ahead of conv2d_2a (HBM latency is several steps)
+constexpr int OFF_IN = 0, OFF_A2 = OFF_IN + IN_RING * IN_ROW, OFF_B2 = OFF_A2 + A2_RING * A2_ROW;
+constexpr int OFF_ZROW = OFF_B2 + B2_RING * B2_ROW;   // zero row (2b's vertical padding)
+constexpr int SM_LDS = OFF_ZROW + A2_ROW;
+
+template <typename T> struct MmaS;
+template <> struct MmaS<__bf16> {
+  static __device__ __forceinline__ f32x4_t run(const uint4& w, const uint4& x, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), c, 0, 0, 0);
+  }
+};
+template <> struct MmaS<_Float16> {
+  static __device__ __forceinline__ f32x4_t run(const uint4& w, const uint4& x, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, x), c, 0, 0, 0);
+  }
+};
+
+// 16-byte chunk `chunk` (0..3 = 8 channels each) of pixel q inside a [px][64 B] row; XOR swizzle as block35.hip
+__device__ __forceinline__ int row_chunk(int q, int chunk) { return q * 64 + ((chunk ^ ((0 - (q >> 2)) & 3)) << 4); }
+
+template <typename T>
+__device__ __forceinline__ uint2 pack4s(const f32x4_t& v) {
+  typedef T t4 __attribute__((ext_vector_type(4)));
+  t4 r = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+  return __builtin_bit_cast(uint2, r);
+}
+
+// max of 8 non-negative 16-bit floats (the rows are ReLU outputs): for values >= 0 the bf16 / f16 bit patterns order
+// like 16-bit integers, so the maximum is four v_pk_max_i16 -- through fp32 converts the pooling alone cost more VALU
+// time than both convolutions' MFMAs
+__device__ __forceinline__ uint4 max8(const uint4& a, const uint4& b) {
+  typedef short s2 __attribute__((ext_vector_type(2)));
+  uint4 r;
+  r.x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, a.x), __builtin_bit_cast(s2, b.x)));
+  r.y = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, a.y), __builtin_bit_cast(s2, b.y)));
+  r.z = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, a.z), __builtin_bit_cast(s2, b.z)));
+  r.w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, a.w), __builtin_bit_cast(s2, b.w)));
+  return r;
+}
+
+}  // namespace
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void stem_mid_kernel(const StemMidArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const int img = blockIdx.x;
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+  const char* __restrict__ xg = (const char*)a.x + (size_t)img * W1A * W1A * a.ldx * 2;
+  char* __restrict__ yg = (char*)a.y + (size_t)img * WP * WP * a.ldy * 2;
+
+  // zero the A2 ring (its padding columns stay zero for the whole kernel) and the zero row
+  for (int i = tid; i < (A2_RING * A2_ROW + A2_ROW) / 16; i += 512) {
+    const int off = i * 16 < A2_RING * A2_ROW ? OFF_A2 + i * 16 : OFF_ZROW + (i * 16 - A2_RING * A2_ROW);
+    *reinterpret_cast<uint4*>(smem + off) = uint4{0u, 0u, 0u, 0u};
+  }
+
+  // 1a row r -> input ring slot r % 6: 5 pieces of 16 px x 64 B; lane -> (px = lane >> 2, physical slot = lane & 3), the
+  // swizzle rides on the source address.  Waves 6, 7 issue 3 pieces each (ids clamp: piece 4 is loaded twice).
+  auto issue_row = [&](int r) {
+    if (wave < 6) return;
+    const int rr = min(r, W1A - 1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int id = min((wave - 6) * 3 + i, 4);
+      const int p = id * 16 + (lane >> 2), slot = lane & 3;
+      const int pc = min(p, W1A - 1);   // pixels 79..: inside the padding of the ring row, any finite data
+      glds16(xg + ((size_t)(rr * W1A + pc) * a.ldx + ((slot ^ ((0 - (p >> 2)) & 3)) << 3)) * 2,
+             lds0 + OFF_IN + (r % IN_RING) * IN_ROW + id * 1024);
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < AHEAD; ++r) issue_row(r);
+
+  // weights: this wave's 9 A-fragments (one per tap), fragment f of tile j at wfrag + ((conv tile base) + f) * 1 KiB
+  const int is2b = wave < 4;
+  const int wtile = is2b ? 2 + wave : (wave & 1);   // image order: 2a tiles 0,1 then 2b tiles 0..3
+  uint4 wf[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wf[t] = reinterpret_cast<const uint4*>(a.wfrag)[(size_t)(wtile * 9 + t) * 64 + lane];
+  const f32x4_t bias = *reinterpret_cast<const f32x4_t*>(a.bias + (is2b ? 32 + 16 * wave : 16 * (wave & 1)) + 4 * fgrp);
+  // pixel tiles of this wave: 2b waves 0..4; 2a waves 4,5: 0..2, waves 6,7: 3..4
+  const int pt0 = is2b ? 0 : (wave < 6 ? 0 : 3), npt = is2b ? 5 : (wave < 6 ? 3 : 2);
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // Per-lane LDS offsets, computed ONCE: a fragment address is (row base, wave-uniform) + (per-lane offset of the tap's
+  // column shift) + (pixel tile) * 1024.  The swizzle term only involves ((pixel >> 2) & 3), which a step of 16 pixels
+  // does not change -- recomputing it per fragment cost ~10 VALU instructions per MFMA and made the kernel VALU-bound.
+  int rd[3];            // read offset of pixel 16*pt0 + frow + k, k = 0..2 (2a: k = dx; 2b: k = dx + 1 with its +1 column pad)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) rd[k] = row_chunk(16 * pt0 + frow + k, fgrp);
+  const int c2a = 16 * (wave & 1) + 4 * fgrp;                                  // 2a output channel of this lane's quad
+  const int st2a = row_chunk(16 * pt0 + frow + 1, c2a >> 3) + (c2a & 4) * 2;   // + i * 1024
+  const int st2b = frow * 128 + (((2 * wave + (fgrp >> 1)) ^ (frow & 7)) << 4) + (fgrp & 1) * 8;   // + i * 2048
+  int pl[2][3];         // pooling: lane item (ox, ch) -> offset of column 2*ox + dx inside a 2b row
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int id = (wave - 4) * 64 + lane + 256 * it, px = 2 * (id >> 3) + dx;
+      pl[it][dx] = px * 128 + (((id & 7) ^ (px & 7)) << 4);
+    }
+
+  // one output row of a 3x3 convolution for NPT pixel tiles.  LDS read latency (~150 cycles) is several MFMAs long, so
+  // fragments are fetched a whole filter row (3 taps x NPT) ahead: two named sets, every index static;
+  // addr(tap, i) = LDS byte address of pixel tile i's B-fragment for that tap.
+  auto conv_row = [&](auto npt_tag, auto addr, f32x4_t* acc) {
+    constexpr int NPT = decltype(npt_tag)::value;
+    uint4 xa[3][NPT], xb[3][NPT];
+    auto load = [&](uint4 (&x)[3][NPT], int t0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) x[d][i] = *reinterpret_cast<const uint4*>(smem + addr(t0 + d, i));
+    };
+    auto mma = [&](const uint4 (&x)[3][NPT], int t0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) acc[i] = MmaS<T>::run(wf[t0 + d], x[d][i], acc[i]);
+    };
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    load(xa, 0);
+    load(xb, 3);
+    mma(xa, 0);
+    load(xa, 6);
+    mma(xb, 3);
+    mma(xa, 6);
+  };
+  using N2 = std::integral_constant<int, 2>;
+  using N3 = std::integral_constant<int, 3>;
+  using N5 = std::integral_constant<int, 5>;
+
+  for (int s = 0; s < 80; ++s) {
+    if (is2b) {
+      const int b = s - 2;   // 2b output row
+      if (b >= 0 && b < W2) {
+        f32x4_t acc[5];
+        int rb[3];   // wave-uniform row bases of the three filter rows (rows -1 and 77: the zero row)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int rr = b + dy - 1;
+          rb[dy] = (rr >= 0 && rr < W2) ? OFF_A2 + (rr % A2_RING) * A2_ROW : OFF_ZROW;
+        }
+        // A2 column of pixel x + dx is x + dx + 1 (pixels live at columns 1..77): offsets rd[0..2]
+        conv_row(N5{}, [&](int tap, int i) { return rb[tap / 3] + rd[tap % 3] + i * 1024; }, acc);
+        char* dst = smem + OFF_B2 + (b % B2_RING) * B2_ROW;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          f32x4_t v = acc[i];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias[e], 0.f);
+          // 2b row: [px][8 chunks of 16 B], chunk index XORed with px & 7 -- unswizzled, the 16 pixels of a store
+          // would sit 128 B apart on ONE bank (16-way conflict on every store of every 2b wave)
+          *reinterpret_cast<uint2*>(dst + st2b + i * 2048) = pack4s<T>(v);
+        }
+      }
+    } else {
+      const int r2 = s;      // 2a output row
+      if (r2 < W2) {
+        f32x4_t acc[3];
+        int rb[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) rb[dy] = OFF_IN + ((r2 + dy) % IN_RING) * IN_ROW;
+        auto addr = [&](int tap, int i) { return rb[tap / 3] + rd[tap % 3] + i * 1024; };
+        if (npt == 3) conv_row(N3{}, addr, acc); else conv_row(N2{}, addr, acc);
+        char* dst = smem + OFF_A2 + (r2 % A2_RING) * A2_ROW;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          if (i < npt) {
+            const int x = 16 * (pt0 + i) + frow;
+            f32x4_t v = acc[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias[e], 0.f);
+            if (x < W2) *reinterpret_cast<uint2*>(dst + st2a + i * 1024) = pack4s<T>(v);
+          }
+      }
+      if (s >= 5 && ((s - 5) & 1) == 0) {
+        // pooled row p from 2b rows 2p, 2p+1, 2p+2: 38 px x 8 chunks of 16 B = 304 items over the 256 lanes of waves 4..7
+        const int p = (s - 5) >> 1;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int id = (wave - 4) * 64 + lane + 256 * it;
+          if (id < WP * 8) {
+            const int ox = id >> 3, ch = id & 7;
+            uint4 m = uint4{0u, 0u, 0u, 0u};   // >= every candidate's floor: the rows hold ReLU outputs
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+              const char* rp = smem + OFF_B2 + ((2 * p + dy) % B2_RING) * B2_ROW;
+#pragma unroll
+              for (int dx = 0; dx < 3; ++dx) m = max8(m, *reinterpret_cast<const uint4*>(rp + pl[it][dx]));
+            }
+            *reinterpret_cast<uint4*>(yg + ((size_t)(p * WP + ox) * a.ldy + ch * 8) * 2) = m;
+          }
+        }
+      }
+    }
+    // Row s+8 goes out now (its slot held row s-4, last read four steps ago).  Row r is first read at step r-2, i.e.
+    // 5 steps after its issue; every step issues >= 3 memory operations per DMA wave, so "all but the 15 youngest
+    // complete" at the end of each step retires every piece at least 5 steps old (pooled stores in the window only make
+    // the wait stricter).
+    if (s + AHEAD < W1A) issue_row(s + AHEAD);
+    if (wave >= 6) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- weight fragments
+// 6 tiles x 9 taps of 1 KiB in MFMA A-fragment order: tiles 0,1 = conv2d_2a channels 0..31, tiles 2..5 = conv2d_2b
+// channels 0..63; lane l of fragment (tile, tap) holds k = 32*tap + 8*(l>>4) .. +7 of output channel 16*tile' + (l&15).
+__global__ void stem_mid_repack_kernel(StemMidPack p, uint4* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int f = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (f >= 54) return;
+  const int tile = f / 9, tap = f % 9;
+  const int conv = tile < 2 ? 0 : 1, r0 = 16 * (tile < 2 ? tile : tile - 2);
+  const char* w = (const char*)p.w[conv];
+  out[(size_t)f * 64 + lane] = *reinterpret_cast<const uint4*>(w + ((size_t)(r0 + (lane & 15)) * p.kpad[conv] + 32 * tap + 8 * (lane >> 4)) * 2);
+}
+
+hipError_t stem_mid_repack(const StemMidPack& p, void* out, hipStream_t s) {
+  hipLaunchKernelGGL(stem_mid_repack_kernel, dim3(14), dim3(256), 0, s, p, (uint4*)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_stem_mid(const StemMidArgs& a, int dtype, hipStream_t s) {
+  if (a.n <= 0) return hipSuccess;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)stem_mid_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS);
+    (void)hipFuncSetAttribute((const void*)stem_mid_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  if (dtype == BF16)
+    hipLaunchKernelGGL(stem_mid_kernel<__bf16>, dim3(a.n), dim3(512), SM_LDS, s, a);
+  else if (dtype == F16)
+    hipLaunchKernelGGL(stem_mid_kernel<_Float16>, dim3(a.n), dim3(512), SM_LDS, s, a);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace vnf
