@@ -16,6 +16,12 @@ for line in open(sys.argv[1]):
         _, n, gf, label = line.rstrip("\n").split(" ", 3)
         for k in range(int(n)):
             plan.append((label + (" #%d" % k if int(n) > 1 else ""), float(gf) / int(n)))
+    elif line.startswith("GROUP_END "):
+        # the launches listed so far repeat once per sub-batch of the stem group
+        rep = int(line.split()[1])
+        if rep > 1:
+            grp = [(l + " [sub-batch %d/%d]" % (r + 1, rep), g / rep) for r in range(rep) for (l, g) in plan]
+            plan = grp
 steps, lanes = int(sys.argv[3]), int(sys.argv[4])
 rows = [r for r in csv.DictReader(open(sys.argv[2])) if "vnf" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))

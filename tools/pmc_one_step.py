@@ -24,6 +24,11 @@ if os.environ.get("VNF_PRINT_PLAN"):
         label = line[:28].strip() or line.split()[0]
         launches = 5 if "fused blocks" in line else 1
         print("PLAN %d %.3f %s" % (launches, gf, label), flush=True)
+        if label.startswith("conv2d_4b"):
+            # the ops up to here form the stem group, which the engine runs once per sub-batch (engine.cpp groups:
+            # 128 images unfused, the whole batch when conv2d_2a/2b/maxpool are fused)
+            chunk = int(os.environ.get("VNF_STEM_CHUNK", "256" if DT in ("bf16", "f16") and (int(os.environ.get("VNF_FUSE", "7")) & 4) else "128"))
+            print("GROUP_END %d" % ((bs + chunk - 1) // chunk), flush=True)
     torch.cuda.synchronize()
     print("PLAN_END", flush=True)
 m.set_streams(1)
