@@ -319,6 +319,87 @@ hipError_t launch_logsoftmax_argmax(const float* logits, int ld, int C, int n, f
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- depthwise 3x3 (MobileNetV1 blocks of RetinaFace)
+// HBM-bound: one thread per (pixel, 4 channels), nine 16-byte loads, taps in (kh, kw) order as the reference's
+// grouped conv sums them
+__global__ void dwconv3x3_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int H, int W, int C, int stride,
+                                 int Ho, int Wo, const float* __restrict__ w9c, const float* __restrict__ bias, float slope) {
+  const int c4 = C >> 2;
+  const size_t total = (size_t)n * Ho * Wo * c4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4) * 4;
+    const size_t p = i / c4;
+    const int wo = (int)(p % Wo);
+    const size_t q = p / Wo;
+    const int ho = (int)(q % Ho);
+    const size_t img = q / Ho;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int hi = ho * stride - 1 + kh, wi = wo * stride - 1 + kw;
+        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+          const f32x4_t v = *reinterpret_cast<const f32x4_t*>(x + ((img * H + hi) * W + wi) * C + c);
+          const f32x4_t ww = *reinterpret_cast<const f32x4_t*>(w9c + (kh * 3 + kw) * C + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = acc[e] + v[e] * ww[e];
+        }
+      }
+    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(bias + c);
+    f32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = acc[e] + b[e];
+      o[e] = v > 0.f ? v : v * slope;
+    }
+    *reinterpret_cast<f32x4_t*>(y + p * C + c) = o;
+  }
+}
+
+hipError_t launch_dwconv3x3(const float* x, float* y, int n, int H, int W, int C, int stride, const float* w9c,
+                            const float* bias, float slope, hipStream_t s) {
+  if (C % 4 || (stride != 1 && stride != 2)) return hipErrorInvalidValue;
+  const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  const size_t total = (size_t)n * Ho * Wo * (C / 4);
+  if (total == 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(blocks), dim3(256), 0, s, x, y, n, H, W, C, stride, Ho, Wo, w9c, bias, slope);
+  return hipGetLastError();
+}
+
+__global__ void upsample_add_kernel(const float* __restrict__ x, int Hs, int Ws, float* __restrict__ y, int H, int W, int C,
+                                    int n, float sh, float sw) {
+  const int c4 = C >> 2;
+  const size_t total = (size_t)n * H * W * c4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4) * 4;
+    const size_t p = i / c4;
+    const int w = (int)(p % W);
+    const size_t q = p / W;
+    const int h = (int)(q % H);
+    const size_t img = q / H;
+    // ATen nearest: min(floor(dst * scale), in - 1) with scale = (float)in / out
+    const int hs = min((int)floorf((float)h * sh), Hs - 1), ws = min((int)floorf((float)w * sw), Ws - 1);
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(y + p * C + c);
+    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(x + ((img * Hs + hs) * Ws + ws) * C + c);
+    f32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = a[e] + b[e];
+    *reinterpret_cast<f32x4_t*>(y + p * C + c) = o;
+  }
+}
+
+hipError_t launch_upsample_add(const float* x, int Hs, int Ws, float* y, int H, int W, int C, int n, hipStream_t s) {
+  if (C % 4) return hipErrorInvalidValue;
+  const size_t total = (size_t)n * H * W * (C / 4);
+  if (total == 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(upsample_add_kernel, dim3(blocks), dim3(256), 0, s, x, Hs, Ws, y, H, W, C, n, (float)Hs / (float)H,
+                     (float)Ws / (float)W);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- NHWC slice -> NCHW fp32 (taps)
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, int ldx, float* __restrict__ y, int n, int HW, int C) {

@@ -952,6 +952,132 @@ int build_onet(Encoder& e, WeightMap& wm) {
   return VNF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// RetinaFace with the MobileNetV1-0.25 backbone (models/retina_face.py:56-152, retina_face_utils/components.py,
+// config.py cfg_mnet) as a plan on the exact-f32 core.  LeakyReLU is the PReLU epilogue with a constant slope;
+// relu(cat(...)) of SSH is a ReLU in each branch's last conv, written into its channel slice (concat-free).
+static bool bn_fold_at(WeightMap& wm, const std::string& p, int C, std::vector<float>& s, std::vector<float>& t) {
+  return bn_fold(wm, p, C, 1e-5f, s, t);
+}
+
+int build_retina_mnet(Encoder& e, WeightMap& wm, int H, int W, int head_bufs[3]) {
+  e.in_size = 0;
+  auto down = [](int v) { return (v + 2 - 3) / 2 + 1; };
+  int cur = e.add_buf(H, W, 4);   // input: NHWC4 (R-104, G-117, B-123, 0)
+  int h = H, w = W;
+  // conv (3x3 or 1x1) + BN + optional LeakyReLU / ReLU into (buf, channel offset)
+  auto conv_bn = [&](const std::string& p, int xb, int cin, int cin_pad, int cout, int k, int stride, int ob, int ooff, int act,
+                     float leaky) -> int {
+    ConvSpec s;
+    s.name = p; s.x_buf = xb; s.cin = cin; s.cin_pad = cin_pad; s.KH = s.KW = k; s.sh = s.sw = stride; s.ph = s.pw = k / 2;
+    s.pieces.resize(1);
+    Piece& pc = s.pieces[0];
+    pc.w = wm.get(p + ".0.weight", (int64_t)cout * cin * k * k);
+    pc.cout = pc.cout_pad = cout;
+    if (!pc.w || !bn_fold_at(wm, p + ".1", cout, pc.scale, pc.bias)) return fail(VNF_E_MISSING, "retina: missing weight " + wm.missing);
+    if (act == ACT_PRELU) pc.slope.assign(cout, leaky);
+    s.segs.push_back({0, cout, ob, ooff});
+    s.act = act;
+    return add_conv(e, s);
+  };
+  // conv_dw(inp, oup, stride): depthwise 3x3 + BN + leaky 0.1, pointwise 1x1 + BN + leaky 0.1 (components.py:30-40)
+  auto conv_dw = [&](const std::string& p, int inp, int oup, int stride) -> int {
+    const float* dw = wm.get(p + ".0.weight", (int64_t)inp * 9);
+    std::vector<float> sc, sh;
+    if (!dw || !bn_fold_at(wm, p + ".1", inp, sc, sh)) return fail(VNF_E_MISSING, "retina: missing weight " + wm.missing);
+    std::vector<float> w9c((size_t)9 * inp);
+    for (int c = 0; c < inp; ++c)
+      for (int t = 0; t < 9; ++t) w9c[(size_t)t * inp + c] = dw[(size_t)c * 9 + t] * sc[c];
+    const int ho = stride == 2 ? down(h) : h, wo = stride == 2 ? down(w) : w;
+    DwLayer d;
+    d.x_buf = cur; d.o_buf = e.add_buf(ho, wo, inp); d.C = inp; d.stride = stride; d.slope = 0.1f;
+    d.w = (float*)e.upload(w9c.data(), w9c.size() * 4);
+    d.bias = (float*)e.upload(sh.data(), sh.size() * 4);
+    if (!d.w || !d.bias) return VNF_E_HIP;
+    e.dws.push_back(d);
+    Op op; op.kind = Op::DWCONV; op.a = (int)e.dws.size() - 1;
+    e.ops.push_back(op);
+    h = ho; w = wo;
+    const int ob = e.add_buf(h, w, oup);
+    // the pointwise half: Sequential indices 3 (conv) and 4 (bn)
+    ConvSpec s;
+    s.name = p + ".3"; s.x_buf = d.o_buf; s.cin = s.cin_pad = inp;
+    s.pieces.resize(1);
+    Piece& pc = s.pieces[0];
+    pc.w = wm.get(p + ".3.weight", (int64_t)oup * inp);
+    pc.cout = pc.cout_pad = oup;
+    if (!pc.w || !bn_fold_at(wm, p + ".4", oup, pc.scale, pc.bias)) return fail(VNF_E_MISSING, "retina: missing weight " + wm.missing);
+    pc.slope.assign(oup, 0.1f);
+    s.segs.push_back({0, oup, ob, 0});
+    s.act = ACT_PRELU;
+    TRY(add_conv(e, s));
+    cur = ob;
+    return VNF_OK;
+  };
+  // ---- body (components.py:100-121)
+  {
+    const int ho = down(h), wo = down(w);
+    const int ob = e.add_buf(ho, wo, 8);
+    TRY(conv_bn("body.stage1.0", cur, 3, 4, 8, 3, 2, ob, 0, ACT_PRELU, 0.1f));
+    cur = ob; h = ho; w = wo;
+  }
+  TRY(conv_dw("body.stage1.1", 8, 16, 1));
+  TRY(conv_dw("body.stage1.2", 16, 32, 2));
+  TRY(conv_dw("body.stage1.3", 32, 32, 1));
+  TRY(conv_dw("body.stage1.4", 32, 64, 2));
+  TRY(conv_dw("body.stage1.5", 64, 64, 1));
+  const int c1 = cur, h1 = h, w1 = w;
+  TRY(conv_dw("body.stage2.0", 64, 128, 2));
+  for (int i = 1; i < 6; ++i) TRY(conv_dw("body.stage2." + std::to_string(i), 128, 128, 1));
+  const int c2 = cur, h2 = h, w2 = w;
+  TRY(conv_dw("body.stage3.0", 128, 256, 2));
+  TRY(conv_dw("body.stage3.1", 256, 256, 1));
+  const int c3 = cur, h3 = h, w3 = w;
+  // ---- FPN (components.py:66-97; out_channels 64 -> leaky 0.1)
+  const int o1 = e.add_buf(h1, w1, 64), o2 = e.add_buf(h2, w2, 64), o3 = e.add_buf(h3, w3, 64);
+  TRY(conv_bn("fpn.output1", c1, 64, 64, 64, 1, 1, o1, 0, ACT_PRELU, 0.1f));
+  TRY(conv_bn("fpn.output2", c2, 128, 128, 64, 1, 1, o2, 0, ACT_PRELU, 0.1f));
+  TRY(conv_bn("fpn.output3", c3, 256, 256, 64, 1, 1, o3, 0, ACT_PRELU, 0.1f));
+  { Op op; op.kind = Op::UPADD; op.a = o3; op.b = o2; e.ops.push_back(op); }
+  const int m2 = e.add_buf(h2, w2, 64);
+  TRY(conv_bn("fpn.merge2", o2, 64, 64, 64, 3, 1, m2, 0, ACT_PRELU, 0.1f));
+  { Op op; op.kind = Op::UPADD; op.a = m2; op.b = o1; e.ops.push_back(op); }
+  const int m1 = e.add_buf(h1, w1, 64);
+  TRY(conv_bn("fpn.merge1", o1, 64, 64, 64, 3, 1, m1, 0, ACT_PRELU, 0.1f));
+  // ---- SSH x3 + heads (components.py:42-64, retina_face.py:20-54,138-146)
+  const int feat_in[3] = {m1, m2, o3}, fh[3] = {h1, h2, h3}, fw[3] = {w1, w2, w3};
+  for (int l = 0; l < 3; ++l) {
+    const std::string p = "ssh" + std::to_string(l + 1);
+    const int cat = e.add_buf(fh[l], fw[l], 64), t5 = e.add_buf(fh[l], fw[l], 16), t7 = e.add_buf(fh[l], fw[l], 16);
+    TRY(conv_bn(p + ".conv3X3", feat_in[l], 64, 64, 32, 3, 1, cat, 0, ACT_RELU, 0.f));
+    TRY(conv_bn(p + ".conv5X5_1", feat_in[l], 64, 64, 16, 3, 1, t5, 0, ACT_PRELU, 0.1f));
+    TRY(conv_bn(p + ".conv5X5_2", t5, 16, 16, 16, 3, 1, cat, 32, ACT_RELU, 0.f));
+    TRY(conv_bn(p + ".conv7X7_2", t5, 16, 16, 16, 3, 1, t7, 0, ACT_PRELU, 0.1f));
+    TRY(conv_bn(p + ".conv7x7_3", t7, 16, 16, 16, 3, 1, cat, 48, ACT_RELU, 0.f));
+    // the three 1x1 heads of the level as one GEMM: columns [class 4 | bbox 8 | landmark 20]
+    const int hb = e.add_buf(fh[l], fw[l], 32);
+    ConvSpec s;
+    s.name = "heads" + std::to_string(l); s.x_buf = cat; s.cin = s.cin_pad = 64;
+    s.pieces.resize(3);
+    const char* hn[3] = {"ClassHead.", "BboxHead.", "LandmarkHead."};
+    const int hc[3] = {4, 8, 20};
+    for (int k = 0; k < 3; ++k) {
+      Piece& pc = s.pieces[k];
+      const std::string q = std::string(hn[k]) + std::to_string(l) + ".conv1x1";
+      pc.w = wm.get(q + ".weight", (int64_t)hc[k] * 64);
+      const float* b = wm.get(q + ".bias", hc[k]);
+      if (!pc.w || !b) return fail(VNF_E_MISSING, "retina: missing weight " + wm.missing);
+      pc.cout = pc.cout_pad = hc[k];
+      pc.bias.assign(b, b + hc[k]);
+    }
+    s.segs.push_back({0, 32, hb, 0});
+    s.act = ACT_NONE;
+    TRY(add_conv(e, s));
+    head_bufs[l] = hb;
+  }
+  return VNF_OK;
+}
+
 // Images are independent, so a batch is cut into `nstreams` contiguous parts that run the whole plan
 // concurrently on side streams (fork / join with events on the caller's stream): the small late
 // layers (a few hundred workgroups, latency-bound) of one part fill the CUs the other leaves idle,
@@ -1159,6 +1285,24 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
                                         op.c, s));
             break;
           }
+          case Op::DWCONV: {
+            if (dtype != F32) return fail(VNF_E_INVALID, "depthwise conv: fp32 plans only");
+            const DwLayer& d = dws[op.a];
+            const Buf& ib = bufs[d.x_buf];
+            const Buf& ob = bufs[d.o_buf];
+            VNF_HIP(launch_dwconv3x3((const float*)ib.ptr + (size_t)n0 * ib.elems_per_image(),
+                                     (float*)ob.ptr + (size_t)n0 * ob.elems_per_image(), nn, ib.H, ib.W, d.C, d.stride, d.w, d.bias,
+                                     d.slope, s));
+            break;
+          }
+          case Op::UPADD: {
+            if (dtype != F32) return fail(VNF_E_INVALID, "upsample-add: fp32 plans only");
+            const Buf& ib = bufs[op.a];
+            const Buf& ob = bufs[op.b];
+            VNF_HIP(launch_upsample_add((const float*)ib.ptr + (size_t)n0 * ib.elems_per_image(), ib.H, ib.W,
+                                        (float*)ob.ptr + (size_t)n0 * ob.elems_per_image(), ob.H, ob.W, ob.C, nn, s));
+            break;
+          }
           case Op::COPYOUT:
             VNF_HIP(hipMemcpyAsync(out + (size_t)n0 * 512, emb_raw + (size_t)n0 * 512, (size_t)nn * 512 * 4,
                                    hipMemcpyDeviceToDevice, s));
@@ -1211,7 +1355,8 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
         snprintf(line, sizeof line, "%-28s %-60s %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n", "conv2d_1a (direct, NCHW in)",
                  "3x3 s2 3->32 on the caller's tensor, VALU packed FMA", ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
       } else {
-        static const char* kn[] = {"pack", "conv", "maxpool", "avgpool", "l2norm", "copyout", "maxpool_ceil", "stem1"};
+        static const char* kn[] = {"pack", "conv", "maxpool", "avgpool", "l2norm", "copyout", "maxpool_ceil", "stem1", "dwconv3x3",
+                                   "upsample_add"};
         snprintf(line, sizeof line, "%-28s %-8s %60s %8.4f ms\n", "", kn[op.kind], "", ms[oi]);
       }
       *report += line;

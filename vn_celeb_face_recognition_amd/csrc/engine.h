@@ -69,8 +69,14 @@ struct ConvLayer {
 };
 
 struct Op {
-  enum Kind { PACK, CONV, MAXPOOL, AVGPOOL, L2NORM, COPYOUT, MAXPOOLC, STEM1 } kind;
+  enum Kind { PACK, CONV, MAXPOOL, AVGPOOL, L2NORM, COPYOUT, MAXPOOLC, STEM1, DWCONV, UPADD } kind;
   int a = 0, b = 0, c = 0, d = 0, e = 0;  // meaning per kind (see engine.cpp)
+};
+
+struct DwLayer {   // depthwise 3x3 pad 1 + folded BN + LeakyReLU (fp32 plans: RetinaFace's MobileNetV1)
+  int x_buf, o_buf, C, stride;
+  float *w = nullptr, *bias = nullptr;   // [9][C], [C]
+  float slope = 0.f;
 };
 
 struct Group { int first, last, chunk; };
@@ -98,6 +104,7 @@ struct Encoder : HandleBase {
   int arch, dtype, max_batch, in_size;
   std::vector<Buf> bufs;
   std::vector<ConvLayer> convs;
+  std::vector<DwLayer> dws;
   std::vector<Op> ops;
   std::vector<Group> groups;
   std::vector<FusedStack> fused;
@@ -133,6 +140,9 @@ int build_irv1(Encoder& e, WeightMap& wm);
 int build_ir100(Encoder& e, WeightMap& wm);
 // MTCNN R-Net / O-Net as exact-f32 MFMA plans over NHWC4 candidate crops (input buffer 0 is written by the
 // crop kernel; the last buffer holds the head outputs: 8 floats [a0,a1,reg0..3,-,-] / 16 floats [a0,a1,reg0..3,lm0..9])
+// RetinaFace (mobilenet0.25) on the exact-f32 core for an H x W input: buffer 0 = NHWC4 mean-subtracted input (written by
+// the caller), head_bufs[l] = (Hl, Wl, 32) fp32 [cls 4 | bbox 8 | landmark 20] of pyramid level l
+int build_retina_mnet(Encoder& e, WeightMap& wm, int H, int W, int head_bufs[3]);
 int build_rnet(Encoder& e, WeightMap& wm);
 int build_onet(Encoder& e, WeightMap& wm);
 

@@ -74,6 +74,15 @@ hipError_t launch_l2norm(const float* x, float* y, int n, int C, hipStream_t s);
 hipError_t launch_logsoftmax_argmax(const float* logits, int ld, int C, int n, float* logp, int32_t* amax, float* prob,
                                     hipStream_t s);
 
+// depthwise 3x3 convolution, padding 1, stride 1 or 2, fp32 NHWC (C % 4 == 0): y = leaky(sum_t x[tap t] * w[t][c] + bias[c])
+// (retina_face_utils/components.py:30-40 conv_dw, first half; BatchNorm folded into w / bias)
+hipError_t launch_dwconv3x3(const float* x, float* y, int n, int H, int W, int C, int stride, const float* w9c,
+                            const float* bias, float slope, hipStream_t s);
+
+// y[n][h][w][c] += x[n][floor(h * Hs/H)][floor(w * Ws/W)][c]: F.interpolate(mode="nearest") + add
+// (retina_face_utils/components.py:88-94), fp32 NHWC
+hipError_t launch_upsample_add(const float* x, int Hs, int Ws, float* y, int H, int W, int C, int n, hipStream_t s);
+
 // NHWC slice (dtype) -> NCHW fp32 (for taps / debugging)
 hipError_t launch_nhwc_to_nchw_f32(const void* x, int ldx, int dtype, float* y, int n, int HW, int C, hipStream_t s);
 

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "nms_device.h"
 
 namespace vnf {
 
@@ -39,7 +40,6 @@ constexpr int CAP_SCALE = 4096;  // candidates per (level, frame) before NMS (12
 constexpr int CAP_IMG = 8192;    // candidates per frame entering the cross-scale NMS
 constexpr int KEEP = 2048;       // survivors per frame after any NMS pass (stage-2 / stage-3 table rows)
 
-enum { ST_OVER_SCALE = 1, ST_OVER_IMG = 2, ST_OVER_KEEP = 4, ST_DEGENERATE = 8 };
 
 struct LevelDesc {
   int Hs, Ws, Hp, Wp, H2, W2, oh, ow;
@@ -322,91 +322,6 @@ __global__ void pnet_conv3_heads_kernel(const float* __restrict__ c2, LevelTable
   }
 }
 
-// --------------------------------------------------------------------------------------------- sort / NMS helpers
-__device__ __forceinline__ unsigned inv_score_bits(float s) { return 0xFFFFFFFFu - __float_as_uint(s); }  // s >= 0
-
-__device__ void block_bitonic_sort(unsigned long long* keys, int npad) {
-  for (int k = 2; k <= npad; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < npad; i += blockDim.x) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const bool up = ((i & k) == 0);
-          const unsigned long long a = keys[i], b = keys[ixj];
-          if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
-        }
-      }
-      __syncthreads();
-    }
-}
-
-__device__ __forceinline__ int next_pow2(int n) {
-  int p = 1;
-  while (p < n) p <<= 1;
-  return p;
-}
-
-// torchvision.ops.nms overlap (area without +1) or nms_numpy 'Min' overlap (areas with +1)
-template <bool MIN_MODE>
-__device__ __forceinline__ bool overlaps(const float4 a, float aa, const float4 b, float ab, float thr) {
-  const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y), xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
-  if (MIN_MODE) {
-    const float w = fmaxf(0.f, xx2 - xx1 + 1.f), h = fmaxf(0.f, yy2 - yy1 + 1.f);
-    const float inter = w * h;
-    return !(inter / fminf(aa, ab) <= thr);
-  } else {
-    const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
-    const float inter = w * h;
-    return inter / (aa + ab - inter) > thr;
-  }
-}
-template <bool MIN_MODE>
-__device__ __forceinline__ float box_area(const float4 b) {
-  return MIN_MODE ? (b.z - b.x + 1.f) * (b.w - b.y + 1.f) : (b.z - b.x) * (b.w - b.y);
-}
-
-// Greedy NMS over n boxes already in visiting order.  getbox(rank) returns the box of the rank-th
-// candidate.  Kept ranks are appended to s_keep (LDS, capacity keep_cap); returns the kept count
-// (uniform).  s_kbox caches the kept boxes, s_cbox / s_alive hold the current chunk.
-template <bool MIN_MODE, typename GetBox>
-__device__ int block_greedy_nms(int n, float thr, GetBox getbox, int* s_keep, float4* s_kbox, int keep_cap,
-                                float4* s_cbox, int* s_alive, int* status) {
-  int nkeep = 0;
-  const int t = threadIdx.x, BS = blockDim.x;
-  for (int base = 0; base < n; base += BS) {
-    const int r = base + t;
-    const bool valid = r < n;
-    float4 box = valid ? getbox(r) : float4{0.f, 0.f, 0.f, 0.f};
-    const float area = box_area<MIN_MODE>(box);
-    bool alive = valid;
-    for (int k = 0; k < nkeep && alive; ++k) {
-      const float4 kb = s_kbox[k];
-      if (overlaps<MIN_MODE>(kb, box_area<MIN_MODE>(kb), box, area, thr)) alive = false;
-    }
-    s_cbox[t] = box;
-    s_alive[t] = alive ? 1 : 0;
-    __syncthreads();
-    const int lim = min(BS, n - base);
-    for (int c = 0; c < lim; ++c) {
-      if (s_alive[c]) {  // block-uniform
-        if (nkeep < keep_cap) {
-          if (t == c) { s_keep[nkeep] = r; s_kbox[nkeep] = box; }
-        } else if (t == 0) {
-          atomicOr(status, ST_OVER_KEEP);
-        }
-        if (nkeep < keep_cap) ++nkeep;
-        if (t > c && alive) {
-          const float4 cb = s_cbox[c];
-          if (overlaps<MIN_MODE>(cb, box_area<MIN_MODE>(cb), box, area, thr)) { alive = false; s_alive[t] = 0; }
-        }
-        __syncthreads();
-      }
-    }
-    __syncthreads();
-  }
-  return nkeep;
-}
-
 __device__ __forceinline__ float4 cell_box(int cell, int ow, float scale) {
   // detect_face.py:214-216: stride 2, cellsize 12; fp32 division by the fp32-rounded scale
   const int y = cell / ow, x = cell - y * ow;
@@ -443,7 +358,7 @@ __global__ void __launch_bounds__(256) nms_scale_kernel(const Cand* __restrict__
   const int ow = t.l[li].ow;
   const float scale = t.l[li].scale;
   auto getbox = [&](int r) { return cell_box(c[(int)(keys[r] & 0xFFF)].cell, ow, scale); };
-  const int nk = block_greedy_nms<false>(n, thr, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
+  const int nk = block_greedy_nms<NMS_TV>(n, thr, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
   Cand* o = keep + (size_t)seg * KEEP;
   for (int k = threadIdx.x; k < nk; k += blockDim.x) o[k] = c[(int)(keys[s_keep[k]] & 0xFFF)];
   if (threadIdx.x == 0) keep_cnt[seg] = nk;
@@ -516,7 +431,7 @@ __global__ void __launch_bounds__(256) nms_image_kernel(const Cand* __restrict__
     const Cand* c = locate((int)(keys[r] & 0xFFFFFFFFu), l);
     return cell_box(c->cell, t.l[l].ow, t.l[l].scale);
   };
-  const int nk = block_greedy_nms<false>(n, thr, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
+  const int nk = block_greedy_nms<NMS_TV>(n, thr, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
   for (int k = threadIdx.x; k < nk; k += blockDim.x) {
     int l;
     const Cand* c = locate((int)(keys[s_keep[k]] & 0xFFFFFFFFu), l);
@@ -1084,7 +999,7 @@ __global__ void __launch_bounds__(256) stage2_post_kernel(const Row* __restrict_
   __syncthreads();
   const int n = s_n;
   auto getbox = [&](int q) { const Row& b = r[(int)(keys[q] & 0xFFFFFFFFu)]; return float4{b.x1, b.y1, b.x2, b.y2}; };
-  const int nk = block_greedy_nms<false>(n, thr_nms, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
+  const int nk = block_greedy_nms<NMS_TV>(n, thr_nms, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
   for (int k = threadIdx.x; k < nk; k += blockDim.x) {
     const int src = (int)(keys[s_keep[k]] & 0xFFFFFFFFu);
     const float4 b = s_kbox[k];
@@ -1141,7 +1056,7 @@ __global__ void __launch_bounds__(256) stage3_post_kernel(const Row* __restrict_
   const int n = s_n;
   auto srcof = [&](int q) { return (int)(keys[q] & 0xFFFFFFFFu); };
   auto getbox = [&](int q) { return s_reg[srcof(q)]; };
-  const int nk = block_greedy_nms<true>(n, thr_nms, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
+  const int nk = block_greedy_nms<NMS_MIN>(n, thr_nms, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
   __syncthreads();
   // final order: area descending (argsort ascending reversed: ties -> later pick first)
   // the score-sorted keys are dead after this: resolve kept ranks to source rows, then reuse `keys`

@@ -1,0 +1,101 @@
+// Block-level sort and greedy NMS shared by the detectors (mtcnn.hip, retina.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace vnf {
+
+enum { ST_OVER_SCALE = 1, ST_OVER_IMG = 2, ST_OVER_KEEP = 4, ST_DEGENERATE = 8 };
+
+// overlap tests: NMS_TV = torchvision.ops.nms (IoU, areas without +1, suppress if > thr); NMS_MIN = detect_face.py
+// nms_numpy 'Min' (inter / min area, +1 widths, keep if <= thr); NMS_IOU1 = py_cpu_nms (IoU with +1 widths, keep if <= thr)
+enum { NMS_TV = 0, NMS_MIN = 1, NMS_IOU1 = 2 };
+
+__device__ __forceinline__ unsigned inv_score_bits(float s) { return 0xFFFFFFFFu - __float_as_uint(s); }  // s >= 0
+
+__device__ inline void block_bitonic_sort(unsigned long long* keys, int npad) {
+  for (int k = 2; k <= npad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const bool up = ((i & k) == 0);
+          const unsigned long long a = keys[i], b = keys[ixj];
+          if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int next_pow2(int n) {
+  int p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+template <int MIN_MODE>
+__device__ __forceinline__ bool overlaps(const float4 a, float aa, const float4 b, float ab, float thr) {
+  const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y), xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
+  if (MIN_MODE == NMS_MIN) {
+    const float w = fmaxf(0.f, xx2 - xx1 + 1.f), h = fmaxf(0.f, yy2 - yy1 + 1.f);
+    const float inter = w * h;
+    return !(inter / fminf(aa, ab) <= thr);
+  } else if (MIN_MODE == NMS_IOU1) {
+    const float w = fmaxf(0.f, xx2 - xx1 + 1.f), h = fmaxf(0.f, yy2 - yy1 + 1.f);
+    const float inter = w * h;
+    return !(inter / (aa + ab - inter) <= thr);
+  } else {
+    const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+    const float inter = w * h;
+    return inter / (aa + ab - inter) > thr;
+  }
+}
+template <int MIN_MODE>
+__device__ __forceinline__ float box_area(const float4 b) {
+  return MIN_MODE != NMS_TV ? (b.z - b.x + 1.f) * (b.w - b.y + 1.f) : (b.z - b.x) * (b.w - b.y);
+}
+
+// Greedy NMS over n boxes already in visiting order.  getbox(rank) returns the box of the rank-th
+// candidate.  Kept ranks are appended to s_keep (LDS, capacity keep_cap); returns the kept count
+// (uniform).  s_kbox caches the kept boxes, s_cbox / s_alive hold the current chunk.
+template <int MIN_MODE, typename GetBox>
+__device__ inline int block_greedy_nms(int n, float thr, GetBox getbox, int* s_keep, float4* s_kbox, int keep_cap,
+                                float4* s_cbox, int* s_alive, int* status) {
+  int nkeep = 0;
+  const int t = threadIdx.x, BS = blockDim.x;
+  for (int base = 0; base < n; base += BS) {
+    const int r = base + t;
+    const bool valid = r < n;
+    float4 box = valid ? getbox(r) : float4{0.f, 0.f, 0.f, 0.f};
+    const float area = box_area<MIN_MODE>(box);
+    bool alive = valid;
+    for (int k = 0; k < nkeep && alive; ++k) {
+      const float4 kb = s_kbox[k];
+      if (overlaps<MIN_MODE>(kb, box_area<MIN_MODE>(kb), box, area, thr)) alive = false;
+    }
+    s_cbox[t] = box;
+    s_alive[t] = alive ? 1 : 0;
+    __syncthreads();
+    const int lim = min(BS, n - base);
+    for (int c = 0; c < lim; ++c) {
+      if (s_alive[c]) {  // block-uniform
+        if (nkeep < keep_cap) {
+          if (t == c) { s_keep[nkeep] = r; s_kbox[nkeep] = box; }
+        } else if (t == 0) {
+          atomicOr(status, ST_OVER_KEEP);
+        }
+        if (nkeep < keep_cap) ++nkeep;
+        if (t > c && alive) {
+          const float4 cb = s_cbox[c];
+          if (overlaps<MIN_MODE>(cb, box_area<MIN_MODE>(cb), box, area, thr)) { alive = false; s_alive[t] = 0; }
+        }
+        __syncthreads();
+      }
+    }
+    __syncthreads();
+  }
+  return nkeep;
+}
+
+
+}  // namespace vnf
