@@ -195,6 +195,34 @@ int vnf_mtcnn_debug_pnet(vnf_handle h, const uint8_t* frames, int height, int wi
 int vnf_mtcnn_debug_stage3(vnf_handle h, const float* boxes, const float* onet_out, int n, float* fin_out,
                            int max_out, int32_t* n_out, void* stream);
 
+/* RetinaFace detector (replaces /root/reference/models/retina_face.py:56-232, the mobilenet0.25 configuration of
+ * cfg/detection/retina_face.json) ---------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t height, width;  /* the exact frame size the handle serves (priors and the plan's buffers are sized for it;
+                           * retina_face.py:180-183 rebuilds its PriorBox per image, here one handle per frame size) */
+  int32_t max_batch;      /* frames per call */
+  float conf_thres;       /* retina_face.py:191-195 (cfg 0.02) */
+  int32_t topk_bf_nms;    /* :198-201 (cfg 5000) */
+  float nms_thres;        /* :204-206 py_cpu_nms (cfg 0.4) */
+  int32_t keep_top_k;     /* :209-210 (cfg 750; <= 768) */
+  float vis_thres;        /* :213-216 (cfg 0.6) */
+} vnf_retina_cfg;
+
+/* weights: the RetinaFace state_dict (body.* / fpn.* / ssh{1,2,3}.* / ClassHead.* / BboxHead.* / LandmarkHead.*, without the
+ * "module." prefix retina_face.py:117-127 strips), fp32 host arrays; BatchNorm is folded (eps 1e-5) at creation. */
+int vnf_retina_create(const vnf_tensor_desc* weights, int n_weights, const vnf_retina_cfg* cfg, vnf_handle* out);
+/* Same contract as vnf_mtcnn_detect: frames = device (B,H,W,3) uint8 RGB; per frame the rows that pass vis_thres in
+ * descending score order.  VNF_E_CAPACITY when a frame has more than 16384 anchors above conf_thres or the total
+ * exceeds max_out.  Synchronises the stream twice (counts, then rows). */
+int vnf_retina_detect(vnf_handle h, const uint8_t* frames, int b, int height, int width,
+                      int32_t* counts, float* boxes, float* probs, float* points, int max_out,
+                      int32_t* n_out, void* stream);
+int vnf_retina_results_device(vnf_handle h, int32_t* frame_idx, float* boxes, float* probs, float* points,
+                              int max_out, void* stream);
+/* staged parity hook: the raw head maps of pyramid level 0..2 of the last detection as a host (b,fh,fw,32) fp32
+ * array, columns [class logits 2x2 | bbox 2x4 | landmarks 2x10]; dims receives {fh, fw}.  Synchronises. */
+int vnf_retina_debug_heads(vnf_handle h, int level, int b, float* host_out, int64_t capacity, int32_t dims[2]);
+
 /* alignment -------------------------------------------------------------------------------- */
 /* For each of n faces: crop rectangle from its box (demo_image.py:179-182), landmarks moved by
  * the float box corner (236-239), Umeyama similarity landmarks -> template (align_face.py:52-54),

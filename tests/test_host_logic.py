@@ -44,7 +44,18 @@ def test_plugin_registry_and_checkpoint_formats(tmp_path):
     for name in ("InceptionResnetV1", "MLPModel", "MTCNN", "iresnet100", "resnet101", "RetinaFace", "resnet_2branch_50"):
         assert hasattr(models, name)
     with pytest.raises(NotImplementedError):
-        models.RetinaFace()
+        models.RetinaFace("cfg_re50")                  # only the mobilenet0.25 configuration is built
+    with pytest.raises(NotImplementedError):
+        models.resnet101()
+    rf = models.RetinaFace("cfg_mnet", device="cpu")
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        rf.inference([np.zeros((32, 32, 3), np.uint8)])
+    # retina_face.py:233-266 checkpoint forms: 'module.' prefixes, optional 'state_dict' level
+    rsd = generate_state_dict("retina", 0, as_torch=True)
+    rp = str(tmp_path / "mobilenet0.25_Final.pth")
+    torch.save({"state_dict": {"module." + k: v for k, v in rsd.items()}}, rp)
+    rf2 = models.RetinaFace("cfg_mnet", device="cpu", checkpoint_path=rp)
+    assert sorted(rf2._sd) == sorted(rsd) and torch.equal(rf2._sd["ssh3.conv7x7_3.0.weight"], rsd["ssh3.conv7x7_3.0.weight"])
     # trainer/base_trainer.py:91-98 checkpoint dict -> demo_image.py:16-21 loader
     sd = generate_state_dict("mlp", 3, as_torch=True, num_classes=16)
     path = str(tmp_path / "model_best.pth")

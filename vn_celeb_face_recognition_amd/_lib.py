@@ -27,6 +27,12 @@ class MtcnnCfg(ctypes.Structure):
                 ("max_width", ctypes.c_int32), ("max_candidates", ctypes.c_int32)]
 
 
+class RetinaCfg(ctypes.Structure):
+    _fields_ = [("height", ctypes.c_int32), ("width", ctypes.c_int32), ("max_batch", ctypes.c_int32),
+                ("conf_thres", ctypes.c_float), ("topk_bf_nms", ctypes.c_int32), ("nms_thres", ctypes.c_float),
+                ("keep_top_k", ctypes.c_int32), ("vis_thres", ctypes.c_float)]
+
+
 _lib = None
 
 # every symbol include/vnface.h declares, with its ctypes signature
@@ -59,6 +65,10 @@ SIGNATURES = {
     "vnf_mtcnn_stage_times": (_I, [_P, _P, _I, _I, _I, ctypes.c_char_p, ctypes.c_int64, _P]),
     "vnf_mtcnn_debug_stage3": (_I, [_P, _P, _P, _I, _P, _I, ctypes.POINTER(ctypes.c_int32), _P]),
     "vnf_mtcnn_debug_pnet": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _P]),
+    "vnf_retina_create": (_I, [ctypes.POINTER(TensorDesc), _I, ctypes.POINTER(RetinaCfg), ctypes.POINTER(_P)]),
+    "vnf_retina_detect": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, ctypes.POINTER(ctypes.c_int32), _P]),
+    "vnf_retina_results_device": (_I, [_P, _P, _P, _P, _P, _I, _P]),
+    "vnf_retina_debug_heads": (_I, [_P, _I, _I, _P, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)]),
     "vnf_align": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _P]),
 }
 

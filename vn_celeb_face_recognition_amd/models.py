@@ -4,6 +4,7 @@ encoder and classifier classes with getattr(models, <name>)(**json_kwargs)
 from .encoders import InceptionResnetV1, iresnet100  # noqa: F401
 from .classifier import MLPModel  # noqa: F401
 from .detector import MTCNN  # noqa: F401
+from .retina import RetinaFace  # noqa: F401
 
 
 def _out_of_scope(name, why):
@@ -14,5 +15,4 @@ def _out_of_scope(name, why):
 
 
 resnet101 = _out_of_scope("resnet101", "alternative encoder, weights not shipped")
-RetinaFace = _out_of_scope("RetinaFace", "alternative detector, weights not shipped")
 resnet_2branch_50 = _out_of_scope("resnet_2branch_50", "emotion recognition")

@@ -12,6 +12,8 @@ travelling.  Key names follow:
   * IResNet-100        -- models/iresnet_encoder.py:26-61 (IBasicBlock), 83-99, 117-137
   * MTCNN P/R/O-Net    -- models/mtcnn.py:19-28, 62-74, 112-128 (real weights ship as
                           weights_mtcnn/*.pt; the synthetic ones are for stress tests only)
+  * RetinaFace (mnet)  -- models/retina_face.py:73-108, retina_face_utils/components.py (the reference downloads
+                          its checkpoint: cfg/detection/retina_face.json points at /content/...)
 
 Distributions are chosen so activations keep O(1) magnitude through >100 layers (He-style conv
 init, BN statistics near identity), which keeps the 1e-4 parity gate meaningful.
@@ -22,13 +24,18 @@ from collections import OrderedDict
 import numpy as np
 
 __all__ = [
-    "irv1_spec", "mlp_spec", "iresnet_spec", "mtcnn_spec", "generate_state_dict",
+    "irv1_spec", "mlp_spec", "iresnet_spec", "mtcnn_spec", "retina_spec", "generate_state_dict",
     "IRV1_MACS_PER_IMAGE", "IR100_MACS_PER_IMAGE",
 ]
 
 # exact algorithmic work per image.
 IRV1_MACS_PER_IMAGE = 1_417_662_304
 IR100_MACS_PER_IMAGE = 12_089_606_144
+
+
+# synthetic RetinaFace class head (see _draw "cls_w" / "cls_b")
+CLS_GAIN = 1.5
+CLS_BIAS = 6.0
 
 
 def _basic_conv(spec, prefix, cin, cout, k):
@@ -175,6 +182,49 @@ def mtcnn_spec(net):
     raise ValueError(net)
 
 
+def retina_spec():
+    """RetinaFace(cfg_mnet).state_dict(): models/retina_face.py:73-108, retina_face_utils/components.py:9-40,100-121
+    (the MobileNetV1 avg / fc layers are dropped by IntermediateLayerGetter, retina_face.py:89)."""
+    s = []
+
+    def conv_bn(p, cin, cout, k=3, first=False):
+        s.append((p + ".0.weight", (cout, cin, k, k), "conv"))
+        _bn(s, p + ".1", cout)
+        if first:   # raw pixels minus the channel means come in at ~70 rms: the stem's BN brings them to O(1)
+            s[-2] = (p + ".1.running_var", (cout,), "bn_v_pix")
+
+    def conv_dw(p, cin, cout):
+        s.append((p + ".0.weight", (cin, 1, 3, 3), "conv"))
+        _bn(s, p + ".1", cin)
+        s.append((p + ".3.weight", (cout, cin, 1, 1), "conv"))
+        _bn(s, p + ".4", cout)
+
+    conv_bn("body.stage1.0", 3, 8, first=True)
+    for i, (a, b) in enumerate([(8, 16), (16, 32), (32, 32), (32, 64), (64, 64)], start=1):
+        conv_dw("body.stage1.%d" % i, a, b)
+    conv_dw("body.stage2.0", 64, 128)
+    for i in range(1, 6):
+        conv_dw("body.stage2.%d" % i, 128, 128)
+    conv_dw("body.stage3.0", 128, 256)
+    conv_dw("body.stage3.1", 256, 256)
+    for i, c in enumerate((64, 128, 256), start=1):
+        conv_bn("fpn.output%d" % i, c, 64, k=1)
+    conv_bn("fpn.merge1", 64, 64)
+    conv_bn("fpn.merge2", 64, 64)
+    for i in (1, 2, 3):
+        p = "ssh%d" % i
+        conv_bn(p + ".conv3X3", 64, 32)
+        conv_bn(p + ".conv5X5_1", 64, 16)
+        conv_bn(p + ".conv5X5_2", 16, 16)
+        conv_bn(p + ".conv7X7_2", 16, 16)
+        conv_bn(p + ".conv7x7_3", 16, 16)
+    for name, width, kind in (("ClassHead", 2, "cls_w"), ("BboxHead", 4, "conv_res"), ("LandmarkHead", 10, "conv_res")):
+        for i in range(3):
+            s.append(("%s.%d.conv1x1.weight" % (name, i), (2 * width, 64, 1, 1), kind))
+            s.append(("%s.%d.conv1x1.bias" % (name, i), (2 * width,), "cls_b" if kind == "cls_w" else "bias"))
+    return s
+
+
 def _draw(rng, shape, kind):
     if kind == "nbt":
         return np.array(0, dtype=np.int64)
@@ -206,6 +256,14 @@ def _draw(rng, shape, kind):
         a = rng.uniform(0.6, 1.4, shape)
     elif kind == "prelu":
         a = rng.uniform(0.1, 0.3, shape)
+    elif kind == "bn_v_pix":
+        a = rng.uniform(3000.0, 7000.0, shape)
+    elif kind == "cls_w":
+        # face / background logits: wide enough that a few anchors in a thousand clear vis_thres (0.6) while ~98 %
+        # stay under conf_thres (0.02), like a trained detector on a frame with a handful of faces
+        a = rng.standard_normal(shape) * np.sqrt(CLS_GAIN / fan_in)
+    elif kind == "cls_b":
+        a = np.where(np.arange(shape[0]) % 2 == 0, CLS_BIAS, -CLS_BIAS) + rng.standard_normal(shape) * 0.05
     else:
         raise ValueError(kind)
     return a.astype(np.float32)
@@ -218,6 +276,7 @@ _SPECS = {
     "pnet": lambda: mtcnn_spec("pnet"),
     "rnet": lambda: mtcnn_spec("rnet"),
     "onet": lambda: mtcnn_spec("onet"),
+    "retina": retina_spec,
 }
 
 
