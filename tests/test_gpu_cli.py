@@ -179,3 +179,42 @@ def test_celeb_statistic_cli(tmp_path):
     os.remove(tmp_path / "t.json")
     out2 = _run([os.path.join(REPO, "celeb_statistic.py")] + common + ["--statistic_mode", "dynamic_itv"], str(tmp_path))
     assert "Re-use tracker file" in out2 and open(tmp_path / "t.json").read() == first
+
+
+def test_face_pipeline_with_the_retinaface_detector(tmp_path):
+    """The detector is a plugin (demo_image.py:361-366): RetinaFace behind the same pipeline -- resident path == stepwise
+    path, and the oracle chain (oracle RetinaFace -> warp -> IRv1 -> MLP) names the same people."""
+    from vn_celeb_face_recognition_amd import models
+    from vn_celeb_face_recognition_amd.classifier import load_model_classify
+    from vn_celeb_face_recognition_amd.cli_utils import read_label2name
+    from vn_celeb_face_recognition_amd.pipeline import (FacePipeline, center_point_dict, parallel_detect_and_align,
+                                                        recognize_celeb, transforms_default)
+    from vn_celeb_face_recognition_amd.synth import make_frames
+    from vn_celeb_face_recognition_amd.weights import generate_state_dict
+    from oracle import retina as oret, align as oalign, irv1 as oirv1, mlp as omlp
+    ck, l2n = _classifier_files(tmp_path)
+    frames = list(make_frames(2, 4, seed=1, height=360, width=640)[0])
+    kw = dict(keep_top_k=5, vis_thres=0.9)
+    det = models.RetinaFace("cfg_mnet", device="cuda:0", max_batch=2, **kw)
+    enc = models.InceptionResnetV1(pretrained=None, compute_dtype="f32", max_batch=16).to("cuda:0").eval()
+    clf = load_model_classify(ck, models.MLPModel(512, 1001)).to("cuda:0")
+    df = read_label2name(l2n)
+    pipe = FacePipeline(det, enc, clf, df, 160, 0.0)
+    names, boxes, emb = pipe.recognize_frames(frames)
+    faces, chosen = parallel_detect_and_align(frames, det, center_point_dict["(160, 160)"], (160, 160))
+    names2 = recognize_celeb(faces, "cuda:0", enc, clf, transforms_default, df, 0.0)
+    assert names == names2 and [len(n) for n in names] == [5, 5]
+    rsd = generate_state_dict("retina", 0, as_torch=True)
+    ob, _, ol = oret.inference(rsd, frames, ties="table", **kw)
+    sd = generate_state_dict("irv1", 0, as_torch=True)
+    msd = generate_state_dict("mlp", 0, as_torch=True)
+    k = 0
+    for i, f in enumerate(frames):
+        for b, l in zip(ob[i], ol[i]):
+            face = oalign.detect_align_faces(f, [b], [l], oalign.CENTER_POINTS["(160, 160)"], 160, 160)[0]
+            e = oirv1.irv1_forward(sd, torch.from_numpy(oalign.transforms_default(face))[None]).numpy()[0]
+            assert np.linalg.norm(emb[k].cpu().numpy() - e) <= 5e-2
+            want, _ = omlp.identify_person(omlp.mlp_forward(msd, torch.from_numpy(e)[None]), df["label"], df["name"], 0.0)
+            assert names[i][k - sum(len(n) for n in names[:i])] == want[0]
+            k += 1
+    assert k == 10

@@ -918,14 +918,19 @@ static void add_pool_ceil(Encoder& e, int ib, int ob, int k) {
   e.ops.push_back(op);
 }
 
-int build_rnet(Encoder& e, WeightMap& wm) {
+// front == true: conv1 + PReLU + pool1 are computed by the detector's own fused kernel (mtcnn.hip net_front_kernel),
+// which reads buffer 0 (the crops) and writes buffer 1 (the pooled map); the plan starts at conv2.
+int build_rnet(Encoder& e, WeightMap& wm, bool front) {
   e.in_size = 24;
-  const int in = e.add_buf(24, 24, 4), c1 = e.add_buf(22, 22, 32), p1 = e.add_buf(11, 11, 32);
+  const int in = e.add_buf(24, 24, 4), p1 = e.add_buf(11, 11, 32);
   const int c2 = e.add_buf(9, 9, 48), p2 = e.add_buf(4, 4, 48), c3 = e.add_buf(3, 3, 64), d4 = e.add_buf(1, 1, 128);
-  const int hd = e.add_buf(1, 1, 8);
+  const int c1 = front ? -1 : e.add_buf(22, 22, 32);
+  const int hd = e.add_buf(1, 1, 8);   // the heads stay the LAST buffer (mtcnn.hip reads bufs.back())
   static thread_local std::vector<float> keep;
-  TRY(mtcnn_conv(e, wm, "conv1", "prelu1", in, 3, 4, 28, 32, 3, c1));
-  add_pool_ceil(e, c1, p1, 3);
+  if (!front) {
+    TRY(mtcnn_conv(e, wm, "conv1", "prelu1", in, 3, 4, 28, 32, 3, c1));
+    add_pool_ceil(e, c1, p1, 3);
+  }
   TRY(mtcnn_conv(e, wm, "conv2", "prelu2", p1, 28, 32, 48, 48, 3, c2));
   add_pool_ceil(e, c2, p2, 3);
   TRY(mtcnn_conv(e, wm, "conv3", "prelu3", p2, 48, 48, 64, 64, 2, c3));
@@ -934,14 +939,18 @@ int build_rnet(Encoder& e, WeightMap& wm) {
   return VNF_OK;
 }
 
-int build_onet(Encoder& e, WeightMap& wm) {
+int build_onet(Encoder& e, WeightMap& wm, bool front) {
   e.in_size = 48;
-  const int in = e.add_buf(48, 48, 4), c1 = e.add_buf(46, 46, 32), p1 = e.add_buf(23, 23, 32);
+  const int in = e.add_buf(48, 48, 4), p1 = e.add_buf(23, 23, 32);
   const int c2 = e.add_buf(21, 21, 64), p2 = e.add_buf(10, 10, 64), c3 = e.add_buf(8, 8, 64), p3 = e.add_buf(4, 4, 64);
-  const int c4 = e.add_buf(3, 3, 128), d5 = e.add_buf(1, 1, 256), hd = e.add_buf(1, 1, 16);
+  const int c4 = e.add_buf(3, 3, 128), d5 = e.add_buf(1, 1, 256);
+  const int c1 = front ? -1 : e.add_buf(46, 46, 32);
+  const int hd = e.add_buf(1, 1, 16);
   static thread_local std::vector<float> keep;
-  TRY(mtcnn_conv(e, wm, "conv1", "prelu1", in, 3, 4, 32, 32, 3, c1));
-  add_pool_ceil(e, c1, p1, 3);
+  if (!front) {
+    TRY(mtcnn_conv(e, wm, "conv1", "prelu1", in, 3, 4, 32, 32, 3, c1));
+    add_pool_ceil(e, c1, p1, 3);
+  }
   TRY(mtcnn_conv(e, wm, "conv2", "prelu2", p1, 32, 32, 64, 64, 3, c2));
   add_pool_ceil(e, c2, p2, 3);
   TRY(mtcnn_conv(e, wm, "conv3", "prelu3", p2, 64, 64, 64, 64, 3, c3));

@@ -30,6 +30,7 @@
 
 #include "engine.h"
 #include "nms_device.h"
+#include "split_f16.h"
 
 namespace vnf {
 
@@ -636,6 +637,102 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
   }
 }
 
+// --------------------------------------------------------------------------------------------- K6a
+// R-Net / O-Net front: conv1 (3 -> 28 / 32, 3x3) + PReLU + MaxPool(3, 2, ceil_mode) in one kernel (mtcnn.py:84-87 /
+// 138-141).  The conv1 map is the largest tensor of the cascade (46x46x32 floats per O-Net candidate, 208 MB for 767
+// candidates); here it only ever exists in LDS.  One workgroup per (band of BANDP pooled rows, candidate): the crop
+// rows the band needs go to LDS, every wave computes all 32 output channels of 16 conv pixels per round on the exact-fp32 MFMA (weights stay
+// in 18 registers per lane), the PReLU outputs are parked in LDS as
+// [pixel][32] with the 16-byte chunk index XOR-swizzled by the pixel, and the pooled rows are reduced from there and
+// written as whole NHWC rows.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+struct FrontW { const float* w; const float* b; const float* a; };   // [32][9 taps][4 channels (3 + zero)], [32], [32]
+
+// SPLIT: the pooled map is written as split-f16 (hi, lo) pairs, the storage of the F16X2 plans (split_f16.h).
+__device__ __forceinline__ float split_pack(float v) {
+  const sf16 h(v);
+  return __builtin_bit_cast(float, h);
+}
+template <int S, int BANDP, int NT, bool SPLIT>
+__global__ void __launch_bounds__(NT) net_front_kernel(const float* __restrict__ crops, FrontW fw, float* __restrict__ p1) {
+  constexpr int C = S - 2;                 // conv1 rows / cols
+  constexpr int P = (C - 3 + 1) / 2 + 1;   // ceil((C - 3) / 2) + 1
+  constexpr int CR = 2 * BANDP + 1;        // conv rows of a band
+  constexpr int IR = CR + 2;               // crop rows of a band
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* s_in = reinterpret_cast<float4*>(smem);                    // [IR][S] NHWC4
+  float4* s_cv = reinterpret_cast<float4*>(smem) + IR * S;           // [CR * C][8 chunks]
+  const int band = blockIdx.x, cand = blockIdx.y, t = threadIdx.x;
+  const int p0 = band * BANDP, np = min(BANDP, P - p0);
+  const int cr0 = 2 * p0, ncr = min(CR, C - cr0), nir = ncr + 2;
+  const float4* src = reinterpret_cast<const float4*>(crops) + ((size_t)cand * S + cr0) * S;
+  for (int i = t; i < nir * S; i += NT) s_in[i] = src[i];
+  __syncthreads();
+  // conv1 as 16x16x4 fp32 MFMAs, one per (tap, 16-channel tile): A = weights (lane: channel l&15, input channel l>>4),
+  // B = crop pixels (lane: pixel l&15, input channel l>>4; channel 3 is the zero pad), D = 4 consecutive output
+  // channels of one pixel per lane.  Same k order as the plan's implicit-GEMM conv (tap-major), bias after the sum.
+  const int wave = t >> 6, lane = t & 63, lg = lane >> 4, lm = lane & 15;
+  float wa[2][9];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) wa[ct][tap] = fw.w[((ct * 16 + lm) * 9 + tap) * 4 + lg];
+  float bias[2][4], slope[2][4];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bias[ct][e] = fw.b[ct * 16 + lg * 4 + e]; slope[ct][e] = fw.a[ct * 16 + lg * 4 + e]; }
+  const int npx = ncr * C;
+  const float* s_inf = reinterpret_cast<const float*>(s_in);
+  for (int tile = wave; tile * 16 < npx; tile += NT / 64) {
+    const int px = tile * 16 + lm, pxc = min(px, npx - 1);
+    const int r = pxc / C, x = pxc - r * C;
+    float xb[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) xb[kh * 3 + kw] = s_inf[((r + kh) * S + x + kw) * 4 + lg];
+    f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][tap], xb[tap], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][tap], xb[tap], acc[1], 0, 0, 0);
+    }
+    if (px < npx) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        float4 o;
+        float* op = reinterpret_cast<float*>(&o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[ct][e] + bias[ct][e];
+          op[e] = v > 0.f ? v : v * slope[ct][e];
+        }
+        s_cv[px * 8 + ((ct * 4 + lg) ^ (px & 7))] = o;
+      }
+    }
+  }
+  __syncthreads();
+  float4* dst = reinterpret_cast<float4*>(p1) + ((size_t)cand * P + p0) * P * 8;
+  for (int i = t; i < np * P * 8; i += NT) {
+    const int q = i & 7, pp = i >> 3, py = pp / P, pxx = pp - py * P;
+    float4 m = float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int rr = 2 * py + dy, xx = 2 * pxx + dx;      // band-local conv row, conv col
+        if (rr < ncr && xx < C) {
+          const int px = rr * C + xx;
+          const float4 v = s_cv[px * 8 + (q ^ (px & 7))];
+          m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+      }
+    if (SPLIT) m = float4{split_pack(m.x), split_pack(m.y), split_pack(m.z), split_pack(m.w)};
+    dst[i] = m;
+  }
+}
+
 // --------------------------------------------------------------------------------------------- K6 building blocks
 // Direct convolution / pooling / dense layers over activations resident in LDS (CHW fp32),
 // weights in their PyTorch layout read through L1/L2 (shared by every workgroup).
@@ -863,17 +960,19 @@ __global__ void prefix_offsets_kernel(const int* __restrict__ cnt, int B, int* _
 // head outputs of the MFMA plans (hw floats per candidate: a0, a1, then the regression / landmark
 // values) -> the per-frame tables the post kernels read: [softmax prob of class 1, values...]
 __global__ void heads_scatter_kernel(const float* __restrict__ heads, int hw, const int* __restrict__ offs,
-                                     const int* __restrict__ cnt, int c0, int cap, float* __restrict__ dst, int nf) {
+                                     const int* __restrict__ cnt, int c0, int cap, float* __restrict__ dst, int nf, int split) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x, img = blockIdx.y;
   if (k >= cnt[img]) return;
   const int ci = offs[img] + k - c0;
   if (ci < 0 || ci >= cap) return;
   const float* hsrc = heads + (size_t)ci * hw;
+  auto val = [&](int i) { return split ? (float)__builtin_bit_cast(sf16, hsrc[i]) : hsrc[i]; };
   float* o = dst + ((size_t)img * KEEP + k) * nf;
-  const float m = fmaxf(hsrc[0], hsrc[1]);
-  const float e0 = expf(hsrc[0] - m), e1 = expf(hsrc[1] - m);
+  const float a0 = val(0), a1 = val(1);
+  const float m = fmaxf(a0, a1);
+  const float e0 = expf(a0 - m), e1 = expf(a1 - m);
   o[0] = e1 / (e0 + e1);
-  for (int i = 1; i < nf; ++i) o[i] = hsrc[1 + i];
+  for (int i = 1; i < nf; ++i) o[i] = val(1 + i);
 }
 
 // mtcnn.py:84-99.  out: [score, reg0..3] per candidate.
@@ -1112,6 +1211,8 @@ struct Mtcnn : HandleBase {
   float *crops = nullptr, *rout = nullptr, *oout = nullptr, *fin = nullptr;
   float *prob_dbg = nullptr, *reg_dbg = nullptr;
   Encoder *renc = nullptr, *oenc = nullptr;  // R-Net / O-Net plans on the exact-f32 MFMA core (candidates = batch)
+  bool front = false;                         // conv1 + PReLU + pool1 of both nets by net_front_kernel (plans start at conv2)
+  FrontW rfw{}, ofw{};
   int r_cap = 0, o_cap = 0;
   int* offs = nullptr;                        // device: (max_batch + 1) compact-batch offsets
   // final read-back: counts block + the first FIN_FAST rows of every frame packed by one kernel into `stage`,
@@ -1262,14 +1363,40 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
         m->renc = new Encoder();
         m->renc->max_streams = 1;  // the detector shares the GPU with the embedding stream: no forks of its own
         m->renc->tune_batch = std::max(1, m->r_cap / 2);  // typical stage-2 load, not the capacity
+        // VNF_MTCNN_DTYPE=f32 keeps the R/O-Net plans on the exact-f32 MFMA; the default is split-f16 (two 16-bit MFMAs per
+        // product, ~22 significant bits) from conv2 on -- conv1 always runs in exact fp32 inside net_front_kernel
+        static const bool plans_f32 = getenv("VNF_MTCNN_DTYPE") && !strcmp(getenv("VNF_MTCNN_DTYPE"), "f32");
         m->renc->kind = 1; m->renc->arch = -2; m->renc->dtype = F32; m->renc->max_batch = m->r_cap;
-        int rr = build_rnet(*m->renc, wr);
+        static const bool front_env = !getenv("VNF_MTCNN_FRONT") || atoi(getenv("VNF_MTCNN_FRONT")) != 0;
+        m->front = front_env;
+        if (m->front && !plans_f32) m->renc->dtype = F16X2;
+        if (m->front) {
+          auto pack_front = [&](WeightMap& wm, int cout, FrontW& fw) -> bool {
+            const float* c1 = wm.get("conv1.weight", (int64_t)cout * 27);
+            const float* b1 = wm.get("conv1.bias", cout);
+            const float* a1 = wm.get("prelu1.weight", cout);
+            if (!c1 || !b1 || !a1) return false;
+            std::vector<float> w(32 * 36, 0.f), b(32, 0.f), a(32, 0.f);
+            for (int co = 0; co < cout; ++co) {
+              for (int c = 0; c < 3; ++c)
+                for (int kh = 0; kh < 3; ++kh)
+                  for (int kw = 0; kw < 3; ++kw) w[(co * 9 + kh * 3 + kw) * 4 + c] = c1[((co * 3 + c) * 3 + kh) * 3 + kw];
+              b[co] = b1[co]; a[co] = a1[co];
+            }
+            fw.w = (const float*)m->upload(w.data(), w.size() * 4);
+            fw.b = (const float*)m->upload(b.data(), b.size() * 4);
+            fw.a = (const float*)m->upload(a.data(), a.size() * 4);
+            return fw.w && fw.b && fw.a;
+          };
+          if (!pack_front(wr, 28, m->rfw) || !pack_front(wo, 32, m->ofw)) { delete m; return fail(VNF_E_MISSING, "mtcnn: conv1 weights"); }
+        }
+        int rr = build_rnet(*m->renc, wr, m->front);
         if (rr == VNF_OK) rr = m->renc->finalize();
         m->oenc = new Encoder();
         m->oenc->max_streams = 1;
         m->oenc->tune_batch = std::max(1, m->o_cap / 4);
-        m->oenc->kind = 1; m->oenc->arch = -3; m->oenc->dtype = F32; m->oenc->max_batch = m->o_cap;
-        if (rr == VNF_OK) rr = build_onet(*m->oenc, wo);
+        m->oenc->kind = 1; m->oenc->arch = -3; m->oenc->dtype = m->renc->dtype; m->oenc->max_batch = m->o_cap;
+        if (rr == VNF_OK) rr = build_onet(*m->oenc, wo, m->front);
         if (rr == VNF_OK) rr = m->oenc->finalize();
         if (rr != VNF_OK) { delete m; return rr; }
       }
@@ -1432,11 +1559,25 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
       const int n = std::min(cap, total - c0);
       crop(rws, cntp, maxc, S, (float*)enc->bufs[0].ptr, m->offs, c0, n);
       mark(S == 24 ? "crop_resize_24" : "crop_resize_48", (double)n * S * S * 16);  // output bytes only (NHWC4 fp32)
-      int rc = enc->run(nullptr, n, VNF_F32, nullptr, s);
+      if (m->front) {
+        const bool split = enc->dtype == F16X2;
+        const float* cin = (const float*)enc->bufs[0].ptr;
+        float* pout = (float*)enc->bufs[1].ptr;
+        const size_t lr = (15 * 24 + 13 * 22 * 8) * 16, lo = (11 * 48 + 9 * 46 * 8) * 16;
+        if (S == 24 && split) hipLaunchKernelGGL((net_front_kernel<24, 6, 256, true>), dim3(2, n), dim3(256), lr, s, cin, m->rfw, pout);
+        else if (S == 24) hipLaunchKernelGGL((net_front_kernel<24, 6, 256, false>), dim3(2, n), dim3(256), lr, s, cin, m->rfw, pout);
+        else if (split) hipLaunchKernelGGL((net_front_kernel<48, 4, 512, true>), dim3(6, n), dim3(512), lo, s, cin, m->ofw, pout);
+        else hipLaunchKernelGGL((net_front_kernel<48, 4, 512, false>), dim3(6, n), dim3(512), lo, s, cin, m->ofw, pout);
+        mark(S == 24 ? "rnet_front" : "onet_front", 0);
+      }
+      static const bool layers = getenv("VNF_MTCNN_LAYERS") != nullptr;   // diagnostic: per-layer table on stderr
+      std::string rep;
+      int rc = enc->run(nullptr, n, VNF_F32, nullptr, s, prof && layers ? &rep : nullptr);
       if (rc != VNF_OK) return rc;
+      if (!rep.empty()) fprintf(stderr, "%s n=%d\n%s", S == 24 ? "rnet" : "onet", n, rep.c_str());
       mark(S == 24 ? "rnet" : "onet", 0);
       hipLaunchKernelGGL(heads_scatter_kernel, dim3((maxc + 63) / 64, B), dim3(64), 0, s, (const float*)enc->bufs.back().ptr, hw,
-                         m->offs, cntp, c0, n, dst, nf);
+                         m->offs, cntp, c0, n, dst, nf, enc->dtype == F16X2 ? 1 : 0);
     }
     return VNF_OK;
   };

@@ -57,10 +57,17 @@ __device__ __forceinline__ float box_area(const float4 b) {
 
 // Greedy NMS over n boxes already in visiting order.  getbox(rank) returns the box of the rank-th
 // candidate.  Kept ranks are appended to s_keep (LDS, capacity keep_cap); returns the kept count
-// (uniform).  s_kbox caches the kept boxes, s_cbox / s_alive hold the current chunk.
+// (uniform).  s_kbox caches the kept boxes, s_cbox / s_alive hold the current chunk.  blockDim.x <= 256.
+//
+// A chunk of blockDim.x candidates is resolved in three parallel steps instead of one barrier per kept box:
+// (1) every candidate is tested against the boxes kept by earlier chunks; (2) every survivor t builds the bit row
+// "later survivors of this chunk that t would suppress"; (3) one lane walks the rows in order (a survivor not yet
+// removed is kept and ORs its row into the removed set) -- the sequential greedy rule, at one LDS read per KEPT box.
 template <int MIN_MODE, typename GetBox>
 __device__ inline int block_greedy_nms(int n, float thr, GetBox getbox, int* s_keep, float4* s_kbox, int keep_cap,
                                 float4* s_cbox, int* s_alive, int* status) {
+  __shared__ unsigned long long s_row[256 * 4];
+  __shared__ unsigned long long s_word[8];   // [0,4): survivors per wave, [4,8): kept per wave
   int nkeep = 0;
   const int t = threadIdx.x, BS = blockDim.x;
   for (int base = 0; base < n; base += BS) {
@@ -75,23 +82,66 @@ __device__ inline int block_greedy_nms(int n, float thr, GetBox getbox, int* s_k
     }
     s_cbox[t] = box;
     s_alive[t] = alive ? 1 : 0;
+    const unsigned long long bal = __ballot(alive);
+    if ((t & 63) == 0) s_word[t >> 6] = bal;
+    if (t < 4 && t * 64 >= BS) s_word[t] = 0;
     __syncthreads();
     const int lim = min(BS, n - base);
-    for (int c = 0; c < lim; ++c) {
-      if (s_alive[c]) {  // block-uniform
-        if (nkeep < keep_cap) {
-          if (t == c) { s_keep[nkeep] = r; s_kbox[nkeep] = box; }
-        } else if (t == 0) {
-          atomicOr(status, ST_OVER_KEEP);
+    unsigned long long m[4] = {0ull, 0ull, 0ull, 0ull};
+    if (alive) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        // survivors after t in word w
+        unsigned long long cand = s_word[w];
+        if (w * 64 + 63 <= t) cand = 0;
+        else if (w * 64 <= t) cand &= ~((2ull << (t & 63)) - 1ull);
+        while (cand) {
+          const int b = __builtin_ctzll(cand);
+          cand &= cand - 1;
+          const float4 cb = s_cbox[w * 64 + b];
+          if (overlaps<MIN_MODE>(box, area, cb, box_area<MIN_MODE>(cb), thr)) m[w] |= 1ull << b;
         }
-        if (nkeep < keep_cap) ++nkeep;
-        if (t > c && alive) {
-          const float4 cb = s_cbox[c];
-          if (overlaps<MIN_MODE>(cb, box_area<MIN_MODE>(cb), box, area, thr)) { alive = false; s_alive[t] = 0; }
-        }
-        __syncthreads();
       }
     }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_row[t * 4 + w] = m[w];
+    __syncthreads();
+    if (t == 0) {
+      unsigned long long rem[4] = {0ull, 0ull, 0ull, 0ull}, kept[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const unsigned long long sv = s_word[w];
+        unsigned long long avail = sv & ~rem[w];
+        while (avail) {
+          const int b = __builtin_ctzll(avail);
+          kept[w] |= 1ull << b;
+          const unsigned long long* row = s_row + (w * 64 + b) * 4;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) rem[v] |= row[v];
+          avail = sv & ~rem[w] & ~((2ull << b) - 1ull);
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s_word[4 + w] = kept[w];
+    }
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned long long kw = s_word[4 + w];
+      const int pc = __popcll(kw);
+      total += pc;
+      if (w < (t >> 6)) before += pc;
+      else if (w == (t >> 6)) before += __popcll(kw & ((1ull << (t & 63)) - 1ull));
+    }
+    const bool kept_me = (s_word[4 + (t >> 6)] >> (t & 63)) & 1ull;
+    if (kept_me) {
+      const int pos = nkeep + before;
+      if (pos < keep_cap) { s_keep[pos] = r; s_kbox[pos] = box; }
+    }
+    if (t == 0 && nkeep + total > keep_cap) atomicOr(status, ST_OVER_KEEP);
+    nkeep = min(keep_cap, nkeep + total);
+    (void)lim;
     __syncthreads();
   }
   return nkeep;
