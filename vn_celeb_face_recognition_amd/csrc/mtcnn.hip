@@ -186,40 +186,221 @@ __global__ void pnet_conv1_pool_kernel(const float* __restrict__ lvl, LevelTable
         const int yy = min(2 * py + dy, L.Hs - 1), xx = min(2 * px + dx, L.Ws - 1);
         in[c][dy][dx] = src[(size_t)c * t.tot_px + yy * L.Ws + xx];
       }
+  // the four conv positions of the pooling window advance together, tap by tap: every weight is fetched once per
+  // thread (they are wave-uniform scalar loads whose latency the FMAs of the previous tap cover), not once per position.
+  // Positions outside (Hc, Wc) are computed on clamped inputs and discarded below.
+  float2_t acc2[4][5];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc2[q][j] = float2_t{w.b1[2 * j], w.b1[2 * j + 1]};
+  // software-pipelined by hand: tap i+1's ten weights are requested before tap i's 20 packed FMAs; the per-tap
+  // barriers keep the compiler from hoisting all 270 scalar loads to the top (they do not fit the SGPR file: it
+  // spilled them to VGPR lanes and paid 3 780 v_readlane for 540 FMAs)
+  float2_t wv[2][5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) wv[0][j] = float2_t{w.w1[2 * j], w.w1[2 * j + 1]};
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap) {
+    const int c = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
+    if (tap + 1 < 27) {
+      const float* ww = w.w1 + (tap + 1) * 10;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) wv[(tap + 1) & 1][j] = float2_t{ww[2 * j], ww[2 * j + 1]};
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float v = in[c][(q >> 1) + kh][(q & 1) + kw];
+      const float2_t v2 = {v, v};
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc2[q][j] = __builtin_elementwise_fma(v2, wv[tap & 1][j], acc2[q][j]);
+    }
+    // every accumulator is made opaque here, so the tap's 20 FMAs cannot be sunk into per-output chains
+    // (LLVM otherwise finishes one accumulator over all 27 taps before starting the next, re-reading every weight)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) asm volatile("" : "+v"(acc2[q][j]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
   float best[10];
 #pragma unroll
   for (int co = 0; co < 10; ++co) best[co] = -INFINITY;
 #pragma unroll
-  for (int oy = 0; oy < 2; ++oy)
+  for (int q = 0; q < 4; ++q) {
+    const bool ok = 2 * py + (q >> 1) < Hc && 2 * px + (q & 1) < Wc;
 #pragma unroll
-    for (int ox = 0; ox < 2; ++ox) {
-      if (2 * py + oy < Hc && 2 * px + ox < Wc) {
-        float2_t acc2[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) acc2[j] = float2_t{w.b1[2 * j], w.b1[2 * j + 1]};
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-          for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-              const float v = in[c][oy + kh][ox + kw];
-              const float2_t v2 = {v, v};
-              const float* ww = w.w1 + ((c * 3 + kh) * 3 + kw) * 10;
-#pragma unroll
-              for (int j = 0; j < 5; ++j) acc2[j] = __builtin_elementwise_fma(v2, float2_t{ww[2 * j], ww[2 * j + 1]}, acc2[j]);
-            }
-#pragma unroll
-        for (int co = 0; co < 10; ++co) {
-          const float av = acc2[co >> 1][co & 1];
-          const float a = av > 0.f ? av : av * w.a1[co];
-          best[co] = fmaxf(best[co], a);
-        }
-      }
+    for (int co = 0; co < 10; ++co) {
+      const float av = acc2[q][co >> 1][co & 1];
+      const float a = av > 0.f ? av : av * w.a1[co];
+      best[co] = ok ? fmaxf(best[co], a) : best[co];
     }
+  }
   float* o = p1 + ((size_t)img * 10) * t.tot_p1 + L.off_p1 + p;
 #pragma unroll
   for (int co = 0; co < 10; ++co) o[(size_t)co * t.tot_p1] = best[co];
+}
+
+// K2 on the matrix pipe.  The per-pixel kernel above needs its 270 weights as wave-uniform scalars at every tap; they
+// do not fit the SGPR file, so each wave fetches them again and again and waits on that (measured: 134 us per 16
+// frames, 30 us with the weights held fixed).  Here the weights are an MFMA operand: 9 VGPRs per lane, loaded once.
+// One workgroup per (pooled row of any level, frame): the four input rows go to LDS, a wave takes tiles of
+// 2 conv rows x 8 conv columns = 16 pixels, one v_mfma_f32_16x16x4_f32 per tap (A = weights [16 ch pad][4 ch pad],
+// B = pixels, accumulator preset with the bias), PReLU, the 2x2 max over the lane quartet {l, l^1, l^8, l^9} by DPP,
+// pooled values staged in LDS and written as whole rows per channel.
+typedef float f32x4p_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float dpp_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor8(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+}
+__device__ __forceinline__ int pnet_row_stride(int Ws) { return ((Ws + 2 + 13) & ~31) + 18 >= Ws + 2 ? ((Ws + 2 + 13) & ~31) + 18 : ((Ws + 2 + 13) & ~31) + 50; }
+
+__global__ void __launch_bounds__(256) pnet_conv1_pool_mfma_kernel(const float* __restrict__ lvl, LevelTable t, PNetW w,
+                                                                    float* __restrict__ p1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int li = 0, py = blockIdx.x;
+  while (li + 1 < t.n && py >= t.l[li].Hp) { py -= t.l[li].Hp; ++li; }
+  const LevelDesc L = t.l[li];
+  const int img = blockIdx.y, tid = threadIdx.x;
+  const int Hc = L.Hs - 2, Wc = L.Ws - 2;
+  const int Wsp = pnet_row_stride(L.Ws);            // LDS row stride: = 18 mod 32 floats, so the (row, channel) lane groups
+  float* s_in = reinterpret_cast<float*>(smem);     // [3 ch][4 rows][Wsp]            spread over the banks
+  float* s_out = s_in + 12 * Wsp;                   // [10][Wp]
+  const float* src = lvl + ((size_t)img * 3) * t.tot_px + L.off_px;
+  for (int i = tid; i < 12 * L.Ws; i += 256) {
+    const int rr = i / L.Ws, x = i - rr * L.Ws, c = rr >> 2, dy = rr & 3;
+    const int yy = min(2 * py + dy, L.Hs - 1);       // a clamped row only feeds conv rows >= Hc, which are masked
+    s_in[rr * Wsp + x] = src[(size_t)c * t.tot_px + yy * L.Ws + x];
+  }
+  const int wave = tid >> 6, lane = tid & 63, lg = lane >> 4, lm = lane & 15, dy = lm >> 3, dx = lm & 7;
+  float wa[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) wa[tap] = (lm < 10 && lg < 3) ? w.w1[(lg * 9 + tap) * 10 + lm] : 0.f;
+  float bias[4], slope[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ch = lg * 4 + e;
+    bias[e] = ch < 10 ? w.b1[ch] : 0.f;
+    slope[e] = ch < 10 ? w.a1[ch] : 0.f;
+  }
+  __syncthreads();
+  const int cg = min(lg, 2);                          // channel 3 is the zero pad of the k dimension (its weights are 0)
+  const bool row_ok = 2 * py + dy < Hc;
+  const int ntile = (L.Wp + 3) >> 2;
+  for (int tx = wave; tx < ntile; tx += 8) {          // tiles tx and tx + 4 together: two accumulator chains interleave
+    f32x4p_t acc[2];
+    float xb[2][9];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int x0 = min(8 * (tx + 4 * u) + dx, L.Ws - 3);   // clamped columns only feed conv columns >= Wc (masked)
+      const float* b0 = s_in + (cg * 4 + dy) * Wsp + x0;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) xb[u][kh * 3 + kw] = b0[kh * Wsp + kw];
+      acc[u] = f32x4p_t{bias[0], bias[1], bias[2], bias[3]};
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[tap], xb[0][tap], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[tap], xb[1][tap], acc[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int txu = tx + 4 * u;
+      const bool ok = row_ok && 8 * txu + dx < Wc;
+      const int pxx = 4 * txu + (dx >> 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[u][e] > 0.f ? acc[u][e] : acc[u][e] * slope[e];
+        v = ok ? v : -INFINITY;
+        v = fmaxf(v, dpp_xor1(v));
+        v = fmaxf(v, dpp_xor8(v));
+        if ((lm & 9) == 0 && pxx < L.Wp && lg * 4 + e < 10) s_out[(lg * 4 + e) * L.Wp + pxx] = v;
+      }
+    }
+  }
+  __syncthreads();
+  float* o = p1 + ((size_t)img * 10) * t.tot_p1 + L.off_p1 + (size_t)py * L.Wp;
+  for (int i = tid; i < 10 * L.Wp; i += 256) {
+    const int ch = i / L.Wp, x = i - ch * L.Wp;
+    o[(size_t)ch * t.tot_p1 + x] = s_out[i];
+  }
+}
+
+// Same arithmetic without the LDS stage: every lane fetches its nine B values straight from the level (the 9-fold
+// reuse between taps and the 2-column overlap of neighbouring tiles are L1 hits), two tiles in flight per wave so the
+// two accumulator chains interleave, the next pair's loads issued before the current pair's MFMAs.  No barrier at all.
+__global__ void __launch_bounds__(256) pnet_conv1_pool_direct_kernel(const float* __restrict__ lvl, LevelTable t, PNetW w,
+                                                                      float* __restrict__ p1) {
+  int li = 0, py = blockIdx.x;
+  while (li + 1 < t.n && py >= t.l[li].Hp) { py -= t.l[li].Hp; ++li; }
+  const LevelDesc L = t.l[li];
+  const int img = blockIdx.y, tid = threadIdx.x;
+  const int Hc = L.Hs - 2, Wc = L.Ws - 2;
+  const int wave = tid >> 6, lane = tid & 63, lg = lane >> 4, lm = lane & 15, dy = lm >> 3, dx = lm & 7;
+  float wa[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) wa[tap] = (lm < 10 && lg < 3) ? w.w1[(lg * 9 + tap) * 10 + lm] : 0.f;
+  float bias[4], slope[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ch = lg * 4 + e;
+    bias[e] = ch < 10 ? w.b1[ch] : 0.f;
+    slope[e] = ch < 10 ? w.a1[ch] : 0.f;
+  }
+  const float* g0 = lvl + ((size_t)img * 3 + min(lg, 2)) * t.tot_px + L.off_px;
+  const float* rowp[3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) rowp[kh] = g0 + (size_t)min(2 * py + dy + kh, L.Hs - 1) * L.Ws;
+  const bool row_ok = 2 * py + dy < Hc;
+  const int ntile = (L.Wp + 3) >> 2;
+  float* o = p1 + ((size_t)img * 10) * t.tot_p1 + L.off_p1 + (size_t)py * L.Wp;
+  auto fetch = [&](int tx, float (&xb)[9]) {
+    const int x0 = min(8 * tx + dx, L.Ws - 3);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) xb[kh * 3 + kw] = rowp[kh][x0 + kw];
+  };
+  auto finish = [&](int tx, f32x4p_t acc) {
+    const bool ok = row_ok && 8 * tx + dx < Wc;
+    const int pxx = 4 * tx + (dx >> 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = acc[e] > 0.f ? acc[e] : acc[e] * slope[e];
+      v = ok ? v : -INFINITY;
+      v = fmaxf(v, dpp_xor1(v));
+      v = fmaxf(v, dpp_xor8(v));
+      if ((lm & 9) == 0 && pxx < L.Wp && lg * 4 + e < 10) o[(size_t)(lg * 4 + e) * t.tot_p1 + pxx] = v;
+    }
+  };
+  // tiles wave, wave+4 form the first pair, then +8 ...; a tile index beyond ntile is clamped for the loads and skipped
+  // (one pooled row per WAVE instead of per workgroup was slower: the long rows of the first level then set the time)
+  float xa[9], xb[9];
+  int tx = wave;
+  if (tx >= ntile) return;
+  fetch(tx, xa);
+  fetch(min(tx + 4, ntile - 1), xb);
+  for (; tx < ntile; tx += 8) {
+    float na[9], nb[9];
+    const int nx = tx + 8;
+    if (nx < ntile) { fetch(nx, na); fetch(min(nx + 4, ntile - 1), nb); }
+    f32x4p_t a0 = {bias[0], bias[1], bias[2], bias[3]}, a1 = a0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[tap], xa[tap], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[tap], xb[tap], a1, 0, 0, 0);
+    }
+    finish(tx, a0);
+    if (tx + 4 < ntile) finish(tx + 4, a1);
+    if (nx < ntile) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { xa[i] = na[i]; xb[i] = nb[i]; }
+    }
+  }
 }
 
 // mtcnn.py:42-43: conv2 10->16 (3x3) + PReLU
@@ -355,7 +536,7 @@ __global__ void __launch_bounds__(256) nms_scale_kernel(const Cand* __restrict__
     keys[i] = i < n ? ((unsigned long long)inv_score_bits(c[i].score) << 32) | ((unsigned long long)(unsigned)c[i].cell << 12) | (unsigned)i
                     : ~0ull;
   __syncthreads();
-  block_bitonic_sort(keys, npad);
+  block_sort(keys, n, npad);
   const int ow = t.l[li].ow;
   const float scale = t.l[li].scale;
   auto getbox = [&](int r) { return cell_box(c[(int)(keys[r] & 0xFFF)].cell, ow, scale); };
@@ -426,7 +607,7 @@ __global__ void __launch_bounds__(256) nms_image_kernel(const Cand* __restrict__
     }
   }
   __syncthreads();
-  block_bitonic_sort(keys, npad);
+  block_sort(keys, n, npad);
   auto getbox = [&](int r) {
     int l;
     const Cand* c = locate((int)(keys[r] & 0xFFFFFFFFu), l);
@@ -514,7 +695,9 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
                                                                 const Row* __restrict__ rows, const int* __restrict__ row_cnt,
                                                                 int S, float* __restrict__ out, int* __restrict__ status,
                                                                 const int* __restrict__ offs, int c0, int cap) {
-  __shared__ __attribute__((aligned(16))) unsigned strips[4][CROP_MAXB + 32];
+  // per-byte column sums of one bin row are at most (rows of a bin) x 255: 16 bits hold 257 rows, deeper bins (frames
+  // taller than ~6000 px at S = 24) take the per-pixel path.  Half the LDS of 32-bit sums -> twice the resident waves.
+  __shared__ __attribute__((aligned(16))) unsigned short strips[4][CROP_MAXB + 32];
   const int k = blockIdx.x, img = blockIdx.y;
   if (k >= row_cnt[img]) return;
   const CropDst d = crop_dst(out, offs, c0, cap, img, k, S);
@@ -533,8 +716,9 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rowb = W * 3, bs = x0 * 3, be = (x0 + cw) * 3;
   const int c_lo = bs >> 4, nch = ((be + 15) >> 4) - c_lo, off = bs - (c_lo << 4);
-  if (nch * 16 > CROP_MAXB + 32 && blockIdx.z != 0) return;
-  if (nch * 16 > CROP_MAXB + 32) {  // wider than a strip: per-pixel path for this candidate
+  const bool slow = nch * 16 > CROP_MAXB + 32 || (ch + S - 1) / S + 1 > 257;
+  if (slow && blockIdx.z != 0) return;
+  if (slow) {  // wider than a strip (or bins too deep for 16-bit sums): per-pixel path for this candidate
     const uint8_t* base = frames + ((size_t)img * H + y0) * (size_t)W * 3 + (size_t)x0 * 3;
     for (int i = threadIdx.x; i < S * S; i += blockDim.x) {
       const int oy = i / S, ox = i - oy * S;
@@ -553,7 +737,7 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
     return;
   }
   const uint8_t* fbase = frames + (size_t)img * H * rowb;
-  unsigned* cs = strips[wave];
+  unsigned short* cs = strips[wave];
   // blockIdx.z splits the S output rows into gridDim.z groups, so one large box (its bins are tens of input rows
   // deep) is spread over several workgroups instead of setting the duration of the whole launch
   const int zrows = (S + (int)gridDim.z - 1) / (int)gridDim.z;
@@ -582,7 +766,8 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
   if (nch <= 32) {
     // narrow crops (the common case: a 100-px box spans ~20 chunks): a wave takes R = 64/nch output rows at
     // once, lane -> (row sub, chunk c), so the loads keep the whole wave busy
-    const int R = 64 / nch, sub = lane / nch, c = lane - sub * nch;
+    // R rows per wave and pass, but no more than spreads the group's rows over the four waves
+    const int R = min(64 / nch, (oy_hi - oy_lo + 3) / 4), sub = lane / nch, c = lane - sub * nch;
     for (int oy0 = oy_lo + wave * R; oy0 < oy_hi; oy0 += 4 * R) {
       const int oy = oy0 + sub;
       if (sub < R && oy < oy_hi) {
@@ -590,7 +775,9 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
         colsum(c, (oy * ch) / S, ((oy + 1) * ch + S - 1) / S, acc);
         uint4* dst = reinterpret_cast<uint4*>(cs + (sub * nch + c) * 16);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dst[j] = uint4{acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+        for (int j = 0; j < 2; ++j)
+          dst[j] = uint4{acc[8 * j] | (acc[8 * j + 1] << 16), acc[8 * j + 2] | (acc[8 * j + 3] << 16),
+                         acc[8 * j + 4] | (acc[8 * j + 5] << 16), acc[8 * j + 6] | (acc[8 * j + 7] << 16)};
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -601,7 +788,7 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
           const int cch = q2 / S, ox = q2 - cch * S;
           const int h0 = (oy2 * ch) / S, h1 = ((oy2 + 1) * ch + S - 1) / S;
           const int w0 = (ox * cw) / S, w1 = ((ox + 1) * cw + S - 1) / S;
-          const unsigned* row = cs + s2 * nch * 16 + off;
+          const unsigned short* row = cs + s2 * nch * 16 + off;
           unsigned sum = 0;
           for (int xx = w0; xx < w1; ++xx) sum += row[xx * 3 + cch];
           o[(oy2 * S + ox) * d.ps + cch * d.cs] = (((float)sum / (float)(h1 - h0)) / (float)(w1 - w0) - 127.5f) * 0.0078125f;
@@ -620,7 +807,9 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
         colsum(c, h0, h1, acc);
         uint4* dst = reinterpret_cast<uint4*>(cs + c * 16);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dst[j] = uint4{acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+        for (int j = 0; j < 2; ++j)
+          dst[j] = uint4{acc[8 * j] | (acc[8 * j + 1] << 16), acc[8 * j + 2] | (acc[8 * j + 3] << 16),
+                         acc[8 * j + 4] | (acc[8 * j + 5] << 16), acc[8 * j + 6] | (acc[8 * j + 7] << 16)};
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1089,7 +1278,7 @@ __global__ void __launch_bounds__(256) stage2_post_kernel(const Row* __restrict_
   for (int i = threadIdx.x; i < npad; i += blockDim.x)
     keys[i] = (i < n0 && ro[i * 5] > thr_score) ? ((unsigned long long)inv_score_bits(ro[i * 5]) << 32) | (unsigned)i : ~0ull;
   __syncthreads();
-  block_bitonic_sort(keys, npad);
+  block_sort(keys, n0, npad);
   if (threadIdx.x == 0) {
     int lo = 0, hi = n0;  // first padded key
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] == ~0ull) hi = mid; else lo = mid + 1; }
@@ -1145,7 +1334,7 @@ __global__ void __launch_bounds__(256) stage3_post_kernel(const Row* __restrict_
   for (int i = threadIdx.x; i < npad; i += blockDim.x)  // ties: earlier row first (see header note on ties)
     keys[i] = (i < n0 && oo[i * 15] > thr_score) ? ((unsigned long long)inv_score_bits(oo[i * 15]) << 32) | (unsigned)i : ~0ull;
   __syncthreads();
-  block_bitonic_sort(keys, npad);
+  block_sort(keys, n0, npad);
   if (threadIdx.x == 0) {
     int lo = 0, hi = n0;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] == ~0ull) hi = mid; else lo = mid + 1; }
@@ -1176,7 +1365,7 @@ __global__ void __launch_bounds__(256) stage3_post_kernel(const Row* __restrict_
     }
   }
   __syncthreads();
-  block_bitonic_sort(keys, kpad);
+  block_sort(keys, nk, kpad);
   float* fo = fin + (size_t)img * KEEP * 15;
   for (int q = threadIdx.x; q < nk; q += blockDim.x) {
     const int k = select_largest ? 0x7FFFFFFF - (int)(keys[q] & 0xFFFFFFFFu) : (int)keys[q];
@@ -1211,6 +1400,7 @@ struct Mtcnn : HandleBase {
   float *crops = nullptr, *rout = nullptr, *oout = nullptr, *fin = nullptr;
   float *prob_dbg = nullptr, *reg_dbg = nullptr;
   Encoder *renc = nullptr, *oenc = nullptr;  // R-Net / O-Net plans on the exact-f32 MFMA core (candidates = batch)
+  int pnet1_lds = 0;                          // dynamic LDS granted to pnet_conv1_pool_mfma_kernel
   bool front = false;                         // conv1 + PReLU + pool1 of both nets by net_front_kernel (plans start at conv2)
   FrontW rfw{}, ofw{};
   int r_cap = 0, o_cap = 0;
@@ -1445,6 +1635,14 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
       const int need_img = CAP_IMG * 8 + KEEP * 20 + 256 * 20, need_scale = CAP_SCALE * 8 + KEEP * 20 + 256 * 20;
       const int need_post = KEEP * 44 + 256 * 20, need_r = (13552 + 3388 + 864) * 4, need_o = (16928 + 14112 + 6912 + 1152) * 4;
       (void)hipFuncSetAttribute((const void*)nms_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_img);
+      {
+        int wmax = 0;
+        for (int l = 0; l < m->cap_table.n; ++l) wmax = std::max(wmax, m->cap_table.l[l].Ws);
+        wmax = (int)(wmax * 1.1) + 64;   // same head-room as the level buffers
+        const int need_p1 = std::min((12 * (wmax + 64) + 10 * ((wmax - 1) / 2)) * 4, 160 * 1024);
+        if (hipFuncSetAttribute((const void*)pnet_conv1_pool_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_p1) == hipSuccess)
+          m->pnet1_lds = need_p1;
+      }
       (void)hipFuncSetAttribute((const void*)nms_scale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_scale);
       (void)hipFuncSetAttribute((const void*)stage2_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_post);
       (void)hipFuncSetAttribute((const void*)stage3_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_post);
@@ -1512,7 +1710,18 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   // algorithmic bytes per launch: what each kernel must read + write once (SURVEY.md 8d terms, from the level table)
   const double fB = (double)B;
   mark("pyramid", fB * ((double)H * W * 3 + (double)t.tot_px * 12));
-  hipLaunchKernelGGL(pnet_conv1_pool_kernel, dim3((t.tot_p1 + 255) / 256, B), dim3(256), 0, s, m->lvl, t, m->pw, m->p1);
+  {
+    int rows = 0, wmax = 0;
+    for (int l = 0; l < t.n; ++l) { rows += t.l[l].Hp; wmax = std::max(wmax, t.l[l].Ws); }
+    const size_t lds = ((size_t)12 * (wmax + 64) + (size_t)10 * ((wmax - 1) / 2)) * 4;
+    static const int p1_mode = getenv("VNF_PNET1") ? atoi(getenv("VNF_PNET1")) : 2;   // 0 VALU, 1 MFMA via LDS, 2 MFMA direct
+    if (p1_mode == 2)
+      hipLaunchKernelGGL(pnet_conv1_pool_direct_kernel, dim3(rows, B), dim3(256), 0, s, m->lvl, t, m->pw, m->p1);
+    else if (p1_mode == 1 && lds <= (size_t)m->pnet1_lds)
+      hipLaunchKernelGGL(pnet_conv1_pool_mfma_kernel, dim3(rows, B), dim3(256), lds, s, m->lvl, t, m->pw, m->p1);
+    else
+      hipLaunchKernelGGL(pnet_conv1_pool_kernel, dim3((t.tot_p1 + 255) / 256, B), dim3(256), 0, s, m->lvl, t, m->pw, m->p1);
+  }
   mark("pnet_conv1_pool", fB * ((double)t.tot_px * 12 + (double)t.tot_p1 * 40));
   hipLaunchKernelGGL(pnet_conv2_kernel, dim3((t.tot_c2 + 255) / 256, B), dim3(256), 0, s, m->p1, t, m->pw, m->c2);
   mark("pnet_conv2", fB * ((double)t.tot_p1 * 40 + (double)t.tot_c2 * 64));

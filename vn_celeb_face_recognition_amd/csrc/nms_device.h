@@ -27,6 +27,45 @@ __device__ inline void block_bitonic_sort(unsigned long long* keys, int npad) {
     }
 }
 
+// Rank sort of n <= E * blockDim.x keys (ascending; unique except for the sentinel ~0, which may repeat): every thread
+// counts the keys below each of its E elements (one broadcast LDS read per key, no barrier inside) and scatters them
+// to their ranks; the sentinels end up behind the real keys.  For the few hundred candidates
+// a frame usually has this is several times cheaper than the log^2 barrier passes of the bitonic network.
+template <int E>
+__device__ inline void block_rank_sort(unsigned long long* keys, int n) {
+  unsigned long long mine[E];
+  int rank[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = threadIdx.x + e * blockDim.x;
+    mine[e] = i < n ? keys[i] : ~0ull;
+    rank[e] = 0;
+  }
+  for (int j = 0; j < n; ++j) {
+    const unsigned long long kj = keys[j];
+#pragma unroll
+    for (int e = 0; e < E; ++e) rank[e] += kj < mine[e] ? 1 : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    if ((int)(threadIdx.x + e * blockDim.x) < n) keys[threadIdx.x + e * blockDim.x] = ~0ull;
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    if (mine[e] != ~0ull) keys[rank[e]] = mine[e];
+  __syncthreads();
+}
+
+// ascending sort of keys[0, n) (unique keys; keys[n, npad) hold ~0 and stay in place)
+__device__ inline void block_sort(unsigned long long* keys, int n, int npad) {
+  const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
+  if (per <= 1) block_rank_sort<1>(keys, n);
+  else if (per == 2) block_rank_sort<2>(keys, n);
+  else if (per <= 4) block_rank_sort<4>(keys, n);
+  else block_bitonic_sort(keys, npad);
+}
+
 __device__ __forceinline__ int next_pow2(int n) {
   int p = 1;
   while (p < n) p <<= 1;

@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) retina_select_kernel(RetinaGeom g, const 
   for (int i = threadIdx.x; i < npad; i += blockDim.x)
     keys[i] = i < n ? ((unsigned long long)inv_score_bits(c[i].score) << 32) | (0xFFFFFFFFu - (unsigned)c[i].anchor) : ~0ull;
   __syncthreads();
-  block_bitonic_sort(keys, npad);
+  block_sort(keys, n, npad);
   // (2) the top-K survive; py_cpu_nms re-sorts them: equal scores now LOWER anchor index first
   const int K = min(n, topk);
   const int kpad = next_pow2(K);
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) retina_select_kernel(RetinaGeom g, const 
     keys[i] = i < K ? (key & 0xFFFFFFFF00000000ull) | (0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu)) : ~0ull;
   }
   __syncthreads();
-  block_bitonic_sort(keys, kpad);
+  block_sort(keys, K, kpad);
   auto anchor_of = [&](int r) { return (int)(keys[r] & 0xFFFFFFFFu); };
   auto getbox = [&](int r) { return decode_box(g, img, anchor_of(r)); };
   // dets are float32 rows [box, score]: the NMS arithmetic is fp32 like py_cpu_nms on that array
