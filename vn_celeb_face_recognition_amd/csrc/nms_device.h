@@ -115,9 +115,17 @@ __device__ inline int block_greedy_nms(int n, float thr, GetBox getbox, int* s_k
     float4 box = valid ? getbox(r) : float4{0.f, 0.f, 0.f, 0.f};
     const float area = box_area<MIN_MODE>(box);
     bool alive = valid;
-    for (int k = 0; k < nkeep && alive; ++k) {
-      const float4 kb = s_kbox[k];
-      if (overlaps<MIN_MODE>(kb, box_area<MIN_MODE>(kb), box, area, thr)) alive = false;
+    // four kept boxes per round (their broadcast LDS reads issue together); the wave leaves once none of its
+    // candidates is alive.  The tail round re-tests the last kept box, which changes nothing.
+    for (int k = 0; k < nkeep; k += 4) {
+      if (__ballot(alive) == 0ull) break;
+      float4 kb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kb[u] = s_kbox[min(k + u, nkeep - 1)];
+      bool hit = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) hit = hit || overlaps<MIN_MODE>(kb[u], box_area<MIN_MODE>(kb[u]), box, area, thr);
+      alive = alive && !hit;
     }
     s_cbox[t] = box;
     s_alive[t] = alive ? 1 : 0;

@@ -252,8 +252,11 @@ extern "C" int vnf_retina_detect(vnf_handle h, const uint8_t* frames, int b, int
     hipLaunchKernelGGL(retina_prep_kernel, dim3((unsigned)std::min<size_t>((npix + 255) / 256, 16384)), dim3(256), 0, s, frames,
                        (float*)e.bufs[0].ptr, npix);
     VNF_HIP(hipGetLastError());
-    int rc = e.run(nullptr, b, VNF_F32, nullptr, s);
+    static const bool layers = getenv("VNF_RETINA_LAYERS") != nullptr;   // diagnostic: per-layer table on stderr
+    std::string rep;
+    int rc = e.run(nullptr, b, VNF_F32, nullptr, s, layers ? &rep : nullptr);
     if (rc != VNF_OK) return rc;
+    if (!rep.empty()) fprintf(stderr, "%s", rep.c_str());
     VNF_HIP(hipMemsetAsync(r->cnt, 0, (2 * (size_t)r->cfg.max_batch + 8) * 4, s));
     hipLaunchKernelGGL(retina_score_kernel, dim3((g.n_anchor + 255) / 256, b), dim3(256), 0, s, g, b, r->cfg.conf_thres, r->cand, r->cnt,
                        r->status);

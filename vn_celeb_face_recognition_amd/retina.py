@@ -110,7 +110,7 @@ class RetinaFace:
         b, h, w, _ = frames.shape
         hd = self._ensure(b, h, w)
         lib = _lib.load()
-        cap = 256
+        cap = b * self.keep_top_k       # a frame never returns more rows than keep_top_k: one call, no capacity retry
         while True:
             counts = np.zeros(b, dtype=np.int32)
             boxes = np.empty((cap, 4), dtype=np.float32)
