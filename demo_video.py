@@ -9,7 +9,8 @@ demo_video.py:186-188); per round the ranks all-gather their embeddings + boxes 
 and rank 0 classifies the gathered tensor and writes the tracker rows in frame order (video.run_stream).
 Annotated frames are written only with -sfr (the reference's test at l.149 is always true and
 PNG-encodes every frame).  Input: a directory of frames, a .npy array of
-(T,H,W,3) RGB frames, or a video file when OpenCV is installed."""
+(T,H,W,3) RGB frames, a Motion-JPEG .avi, or any video file when OpenCV is installed; -ov exports the annotated frames
+as a video (MP4V with OpenCV, Motion-JPEG .avi without)."""
 import os
 import time
 
@@ -20,7 +21,8 @@ import torch.distributed as dist
 from demo_image import build_models, build_parser
 from vn_celeb_face_recognition_amd import dist as vdist
 from vn_celeb_face_recognition_amd.cli_utils import (append_log_to_file, convert_sec_to_max_time_quantity,
-                                                     draw_boxes_on_image, open_frame_source, write_rgb)
+                                                     draw_boxes_on_image, export_video_face_recognition, open_frame_source,
+                                                     write_rgb)
 from vn_celeb_face_recognition_amd.pipeline import FacePipeline
 from vn_celeb_face_recognition_amd.video import run_stream, tracker_row  # noqa: F401  (tracker_row: part of this module's surface)
 
@@ -73,8 +75,9 @@ if __name__ == '__main__':
     if args.inference_method != 'par_fd_vs_aln':
         raise SystemExit("use --inference_method par_fd_vs_aln (seq_fd_vs_aln needs the FAN landmark network, outside "
                          "the hot path and broken in the reference for list input)")
-    if args.output_video:
-        raise SystemExit("-ov needs OpenCV's VideoWriter, which is not installed; keep the frames with -sfr")
+    if args.output_video and not args.save_frame_recognized:
+        raise SystemExit("-ov assembles the annotated frames of --output_frame: add -sfr (the reference writes every frame "
+                         "unconditionally, demo_video.py:149)")
     rank, world, local = vdist.init_from_env()
     device = 'cuda:%d' % local
     torch.cuda.set_device(local)
@@ -82,5 +85,7 @@ if __name__ == '__main__':
     pipe = FacePipeline(detection_md, emb_model, classify_model, label2name_df, args.target_face_size, args.recog_threshold,
                         embed_batch=256)
     main(args, pipe, rank, world, device=device)
+    if args.output_video and rank == 0:
+        export_video_face_recognition(args.output_frame, args.fps_video, args.output_video)     # demo_video.py:285-287
     if world > 1:
         dist.destroy_process_group()

@@ -147,6 +147,22 @@ def test_demo_image_and_demo_video_cli(tmp_path):
     assert lines[4].endswith(',"[]",4,"[]"')                   # the blank frame
     assert lines[1].split(",")[0] == "0.04" and '"[\'celeb_' in lines[1] or "Unknown" in lines[1]
     assert sorted(os.listdir(tmp_path / "of")) == ["frame_%d.png" % i for i in range(1, 6)]
+    # container in, container out (demo_video.py:25-43,78-110) without OpenCV: Motion-JPEG AVI both ways
+    from vn_celeb_face_recognition_amd.mjpeg_avi import read_mjpeg_avi, write_mjpeg_avi
+    from vn_celeb_face_recognition_amd.cli_utils import read_rgb
+    vin = str(tmp_path / "in.avi")
+    write_mjpeg_avi(vin, (read_rgb(str(fd / ("f_%02d.png" % i))) for i in range(5)), 25.0, quality=97)
+    trk2, vout = str(tmp_path / "tracker2.csv"), str(tmp_path / "out.avi")
+    so = _run([os.path.join(REPO, "demo_video.py"), "-i", vin, "-o", str(tmp_path / "of2"), "-ot", trk2, "--n_frames", "2", "-sfr",
+               "-ov", vout, "-fps", "25"] + common, str(tmp_path))
+    assert "Save exported video in" in so
+    lines2 = open(trk2).read().splitlines()
+    assert len(lines2) == 6 and lines2[4].endswith(',"[]",4,"[]"')
+    assert [l.split(",")[0] for l in lines2[1:]] == [l.split(",")[0] for l in lines[1:]]          # same time stamps (25 fps)
+    assert [l.count("celeb_") + l.count("Unknown") for l in lines2[1:]] == [l.count("celeb_") + l.count("Unknown") for l in lines[1:]]
+    fps, frames, n = read_mjpeg_avi(vout)
+    frames = list(frames)
+    assert n == 5 and fps == 25.0 and frames[0].shape == a.shape
 
 
 def test_celeb_statistic_cli(tmp_path):

@@ -277,3 +277,38 @@ def test_oracle_warp_identity_translation_and_border():
     assert np.array_equal(out[:, 1:], want.astype(np.uint8))
     T = align.umeyama(np.array([[0, 0], [1, 0], [0, 1], [1, 1], [0.5, 0.5]]) * 3 + 2, np.array([[0, 0], [1, 0], [0, 1], [1, 1], [0.5, 0.5]]))
     assert np.allclose(T, [[1 / 3, 0, -2 / 3], [0, 1 / 3, -2 / 3], [0, 0, 1]], atol=1e-12)
+
+
+def test_mjpeg_avi_round_trip_and_export(tmp_path):
+    """mjpeg_avi.py: the container the CLIs read / write without OpenCV (demo_video.py:25-43,78-110)."""
+    from PIL import Image
+    from vn_celeb_face_recognition_amd.cli_utils import export_video_face_recognition, open_frame_source
+    from vn_celeb_face_recognition_amd.mjpeg_avi import read_mjpeg_avi, write_mjpeg_avi
+    yy, xx = np.mgrid[0:96, 0:128]
+    frames = [np.stack([(xx * 2 + 10 * i) % 256, (yy * 2) % 256, (xx + yy) % 256], axis=-1).astype(np.uint8) for i in range(7)]
+    p = str(tmp_path / "a.avi")
+    assert write_mjpeg_avi(p, frames, 29.97, quality=95) == 7
+    fps, gen, n = read_mjpeg_avi(p)
+    got = list(gen)
+    assert abs(fps - 29.97) < 1e-9 and n == 7 and len(got) == 7 and got[0].shape == (96, 128, 3)
+    assert max(np.abs(g.astype(int) - f.astype(int)).mean() for g, f in zip(got, frames)) < 3.0     # JPEG, quality 95
+    src = open_frame_source(p)                       # the CLI path: FrameSource over the decoded stream
+    assert abs(src.fps - 29.97) < 1e-9
+    with pytest.raises(ValueError):
+        write_mjpeg_avi(str(tmp_path / "b.avi"), [frames[0], frames[1][:50]], 25)
+    bad = tmp_path / "c.avi"
+    bad.write_bytes(b"RIFF\x04\x00\x00\x00WAVE")
+    with pytest.raises(ValueError):
+        read_mjpeg_avi(str(bad))
+    with pytest.raises(RuntimeError, match="Motion-JPEG"):
+        open_frame_source(str(tmp_path / "movie.mp4"))
+    # export: frame_1.png .. frame_N.png -> video (demo_video.py:25-43)
+    od = tmp_path / "of"; od.mkdir()
+    for i, f in enumerate(frames[:4], start=1):
+        Image.fromarray(f).save(od / ("frame_%d.png" % i))
+    out = str(tmp_path / "out.avi")
+    export_video_face_recognition(str(od), 12.5, out)
+    fps2, gen2, n2 = read_mjpeg_avi(out)
+    assert fps2 == 12.5 and n2 == 4
+    with pytest.raises(RuntimeError, match=".avi"):
+        export_video_face_recognition(str(od), 12.5, str(tmp_path / "out.mp4"))

@@ -58,10 +58,39 @@ def draw_boxes_on_image(rgb_image, boxes, list_names):
     return np.asarray(im)
 
 
+def export_video_face_recognition(output_frame_dir, fps, output_path):
+    """demo_video.py:25-43: frame_1.png .. frame_N.png of the output directory -> one video.  cv2.VideoWriter (MP4V) when
+    OpenCV is importable; otherwise a Motion-JPEG AVI (output_path must end in .avi)."""
+    import glob
+    import os
+    n_images = len(glob.glob(os.path.join(output_frame_dir, '*')))
+    paths = [os.path.join(output_frame_dir, 'frame_{}.png'.format(i)) for i in range(1, n_images + 1)]
+    paths = [p for p in paths if os.path.exists(p)]
+    if not paths:
+        raise RuntimeError("export_video_face_recognition: no frame_<i>.png under %r (run with -sfr)" % output_frame_dir)
+    try:
+        import cv2
+    except ImportError:
+        cv2 = None
+    if cv2 is not None:
+        first = cv2.imread(paths[0])
+        out_writer = cv2.VideoWriter(output_path, cv2.VideoWriter_fourcc(*'MP4V'), fps, (first.shape[1], first.shape[0]))
+        for pth in paths:
+            out_writer.write(cv2.imread(pth))
+        out_writer.release()
+    else:
+        if not output_path.lower().endswith('.avi'):
+            raise RuntimeError("without OpenCV the exported video is a Motion-JPEG AVI: give -ov a name ending in .avi")
+        from .mjpeg_avi import write_mjpeg_avi
+        write_mjpeg_avi(output_path, (read_rgb(pth) for pth in paths), fps)
+    print('Save exported video in {} ...'.format(output_path))
+
+
 def open_frame_source(path):
     """video.FrameSource over RGB frames.  Accepts a directory of images (sorted; random access: a rank decodes only its
-    own batches), a .npy/.npz array of (T,H,W,3) uint8 frames (memory-mapped), or a video file when OpenCV is
-    importable (demo_video.py:78-81; sequential: the other ranks' frames are decoded and dropped)."""
+    own batches), a .npy/.npz array of (T,H,W,3) uint8 frames (memory-mapped), a Motion-JPEG .avi (pure-Python RIFF
+    walker, mjpeg_avi.py), or any video file when OpenCV is importable (demo_video.py:78-81; sequential: the other
+    ranks' frames are decoded and dropped)."""
     import os
     from .video import FrameSource
     if os.path.isdir(path):
@@ -74,8 +103,15 @@ def open_frame_source(path):
     try:
         import cv2
     except ImportError:
-        raise RuntimeError("decoding %r needs OpenCV, which is not installed: pass a directory of frames or a .npy "
-                           "array of (T,H,W,3) uint8 RGB frames instead" % path)
+        cv2 = None
+    if cv2 is None:
+        from .mjpeg_avi import read_mjpeg_avi
+        try:
+            fps, frames, _ = read_mjpeg_avi(path)
+        except (ValueError, OSError) as e:
+            raise RuntimeError("decoding %r needs OpenCV, which is not installed (%s): pass a Motion-JPEG .avi, a directory "
+                               "of frames or a .npy array of (T,H,W,3) uint8 RGB frames instead" % (path, e))
+        return FrameSource(frames, fps)
     cap = cv2.VideoCapture(path)
     fps = cap.get(cv2.CAP_PROP_FPS) or 25.0
 
