@@ -109,6 +109,7 @@ def run_detect(args):
     from vn_celeb_face_recognition_amd import models
     from vn_celeb_face_recognition_amd.pipeline import align_faces_device, center_point_dict
     from vn_celeb_face_recognition_amd.synth import make_frames
+    from vn_celeb_face_recognition_amd.streams import side_stream
     if args.gpus != 1:
         raise SystemExit("--workload detect is a single-GPU line (frames shard like the pipeline workload)")
     dev = torch.device("cuda", 0)
@@ -123,7 +124,7 @@ def run_detect(args):
 
     def work(k, first, n):
         torch.cuda.set_device(dev)
-        st = torch.cuda.Stream(device=dev)
+        st = side_stream(dev, k)
         with torch.cuda.stream(st):
             for i in range(first, first + n):
                 counts, boxes, probs, points = dets[k].detect_device(batches[i & 1])
@@ -299,7 +300,8 @@ def embed_leg(args, dtype, rank, world, dev, n_lanes, steps, warmup, want_cpu, w
     # activation-buffer contexts (vnf_encoder_set_contexts) with whole-batch launches (no internal half-batch forks):
     # the latency-bound tail of one batch overlaps the throughput-bound stem of the next.  Every step's work is
     # complete when the timed region's closing synchronize returns.
-    lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, n_lanes))]
+    from vn_celeb_face_recognition_amd.streams import side_streams
+    lanes = side_streams(dev, max(1, n_lanes))     # process-wide stream objects (streams.py)
     if len(lanes) > 1:
         model.set_streams(1)
         model.set_contexts(len(lanes))
@@ -451,6 +453,22 @@ def main():
     pipe_lanes = args.lanes if args.lanes > 0 else 1
 
     out = None
+    p = None
+    pipe_first = os.environ.get("BENCH_PIPE_FIRST", "0") != "0"
+
+    def run_pipeline():
+        st = args.steps if args.workload == "pipeline" else max(10, args.steps // 2)
+        try:
+            return pipeline_leg(args, rank, world, local, st, args.warmup, pipe_lanes, want_cpu)
+        except Exception as e:
+            if args.workload == "pipeline":
+                raise
+            return {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # legs of one process share the package's process-wide side streams (streams.py): with fresh streams per leg the
+    # second leg's streams could share a hardware queue and lose 15-20 %
+    if args.workload in ("all", "pipeline") and pipe_first:
+        p = run_pipeline()
     if args.workload in ("all", "embed"):
         out = embed_leg(args, args.dtype, rank, world, dev, emb_lanes, args.steps, args.warmup, want_cpu)
     if args.workload == "all" and args.model == "irv1":
@@ -466,19 +484,13 @@ def main():
                 legs[dt] = r if "error" in r else {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "parity") if k in r}
         if rank == 0:
             out["legs"] = legs
-    if args.workload in ("all", "pipeline"):
-        st = args.steps if args.workload == "pipeline" else max(10, args.steps // 2)
-        try:
-            p = pipeline_leg(args, rank, world, local, st, args.warmup, pipe_lanes, want_cpu)
-        except Exception as e:
-            if args.workload == "pipeline":
-                raise
-            p = {"error": "%s: %s" % (type(e).__name__, e)}
-        if rank == 0:
-            if args.workload == "pipeline":
-                out = p
-            else:
-                out["pipeline"] = p
+    if args.workload in ("all", "pipeline") and not pipe_first:
+        p = run_pipeline()
+    if rank == 0 and args.workload in ("all", "pipeline"):
+        if args.workload == "pipeline":
+            out = p
+        else:
+            out["pipeline"] = p
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

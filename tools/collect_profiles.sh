@@ -28,6 +28,9 @@ python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err || exit 1
 python bench.py --workload detect --detectors 2 > $OUT/${R}_bench_detect.json 2>/dev/null || exit 1
 python bench.py --workload embed --model ir100 --no-cpu-baseline > $OUT/${R}_bench_ir100.json 2>/dev/null || exit 1
 python tools/profile_encoder.py 256 bf16 > $OUT/${R}_irv1_bs256_bf16_layer_times.txt 2>/dev/null || exit 1
+# 3b. detector stage / layer tables (MTCNN cascade on 16 x 1080p; RetinaFace swap-in detector)
+python tools/mtcnn_layers.py > $OUT/${R}_mtcnn_stage_times.txt 2>&1 || exit 1
+VNF_RETINA_LAYERS=1 python tools/retina_time.py 1080 1920 16 3 > $OUT/${R}_retina_1080p.txt 2>&1 || exit 1
 # 4. kernel-trace summary of the same default bench command (embed legs + pipeline leg)
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/kt_bench -o b --output-format csv -- python3 $ROOT/bench.py --no-cpu-baseline --legs "" > $OUT/kt_bench.log 2>&1 || exit 1

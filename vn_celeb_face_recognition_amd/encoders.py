@@ -163,7 +163,8 @@ class _Encoder:
         if lanes > 1:
             self.set_streams(1)
             self.set_contexts(lanes)
-        streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        from .streams import side_streams
+        streams = side_streams(dev, lanes)      # process-wide stream objects (streams.py: hardware-queue binding)
         start = torch.cuda.current_stream(dev).record_event()
         for s_ in streams:
             s_.wait_event(start)

@@ -322,8 +322,12 @@ class FacePipeline:
         `ticket.result()` returns them in submission order regardless of completion order."""
         dev = frames_dev.device
         if self._det_streams is None:
-            self._det_streams = [torch.cuda.Stream(device=dev) for _ in self.detectors]
-            self._emb_streams = [torch.cuda.Stream(device=dev) for _ in range(self.embed_lanes)]
+            # process-wide stream objects, roles in a fixed order (streams.py: a fresh pair per pipeline can end up on
+            # one hardware queue and serialise detection with embedding)
+            from .streams import side_streams
+            nd = len(self.detectors)
+            self._det_streams = [side_streams(dev, 1, 0)[0]] + side_streams(dev, nd - 1, 1 + self.embed_lanes)
+            self._emb_streams = side_streams(dev, self.embed_lanes, 1)
             self._emb_stream = self._emb_streams[0]
             self._acc = [None] * self.embed_lanes
             if hasattr(self.encoder, "set_streams"):

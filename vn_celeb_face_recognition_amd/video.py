@@ -86,7 +86,11 @@ def run_stream(source, pipe, n_frames, rank=0, world=1, device=None, on_frame=No
     requesting it makes every rank classify the gathered embeddings (the names are needed where the pixels are).
     Returns (rows: {frame_number: csv row}, complete on rank 0; frames processed by this rank)."""
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-    comm = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+    if dev.type == "cuda":
+        from .streams import side_stream
+        comm = side_stream(dev, 7)          # the collective's stream (roles 0..6 belong to the pipeline, streams.py)
+    else:
+        comm = None
     classify_here = rank == 0 or on_frame is not None
     rows, inflight = {}, []        # inflight: (round, ticket or None, frames, info)
     state = {"processed": 0, "shape": None}
