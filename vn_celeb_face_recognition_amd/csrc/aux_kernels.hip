@@ -1,5 +1,6 @@
 // HBM-bound helper kernels around the convolution core: layout packing, pooling, L2 norm.
 // All are coalesced streaming kernels (16-byte accesses along the NHWC channel axis).
+#include <algorithm>
 #include "kernels.h"
 #include "split_f16.h"
 
@@ -365,6 +366,178 @@ hipError_t launch_dwconv3x3(const float* x, float* y, int n, int H, int W, int C
   if (total == 0) return hipSuccess;
   const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   hipLaunchKernelGGL(dwconv3x3_kernel, dim3(blocks), dim3(256), 0, s, x, y, n, H, W, C, stride, Ho, Wo, w9c, bias, slope);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RetinaFace / MobileNetV1-0.25 early layers on the MFMA lane layout (fp32, exact v_mfma_f32_16x16x4_f32).
+//
+// The first layers of that network are pure data movement (a 1080p frame is 33 MB as NHWC4 fp32, conv0's output 133 MB,
+// the 8->16 pointwise output 265 MB per 8 frames ...), with channel counts (3, 8, 16, 32) far below what the tiled
+// implicit-GEMM kernel is built for.  Two kernels replace them:
+//   * retina_stem_kernel: u8 RGB frame -> (x - mean) -> 3x3 stride-2 pad-1 conv 3->8 + folded BN + LeakyReLU, straight
+//     from the frame bytes (no NHWC4 fp32 staging tensor).  One wave = 16 output pixels: B = the 27 taps of a pixel
+//     (k = (kh*3+kw)*3 + c, lane group = k mod 4), A = weights (7 VGPRs), one MFMA per 4 k.
+//   * dwpw_kernel<CIN,COUT>: depthwise 3x3 (+BN+LeakyReLU) and the pointwise 1x1 (+BN+LeakyReLU) that follows it in
+//     conv_dw (components.py:30-40) in one pass: lane (pixel l&15, group l>>4) computes the depthwise outputs of
+//     channels {4s + group}, which is exactly the B operand of k-step s of the pointwise GEMM; the depthwise tensor
+//     never reaches memory.  Depthwise arithmetic (mul, add, tap order) is that of dwconv3x3_kernel.
+struct RetinaStemW { const float* wa; const float* bias; float slope; };   // wa: [7][64] lane table, bias[8]
+
+__global__ void __launch_bounds__(256) retina_stem_kernel(const uint8_t* __restrict__ frames, int n, int H, int W, int Ho, int Wo,
+                                                           RetinaStemW w, float* __restrict__ y) {
+  // (tried and slower: four tiles in flight per wave, 0.15 ms per 8 frames; rows staged as aligned dwords in a
+  // wave-private LDS strip, 0.19 ms; this form: 0.13 ms against 0.46 ms for the staging pass + plan convolution)
+  const int lane = threadIdx.x & 63, lg = lane >> 4, lm = lane & 15;
+  float wa[7];
+#pragma unroll
+  for (int s = 0; s < 7; ++s) wa[s] = w.wa[s * 64 + lane];
+  float b4[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b4[e] = lg < 2 ? w.bias[lg * 4 + e] : 0.f;
+  const int tiles_w = (Wo + 15) >> 4;
+  const long long ntile = (long long)n * Ho * tiles_w;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
+  for (long long t = wave; t < ntile; t += nwave) {
+    const int tw = (int)(t % tiles_w);
+    const long long q = t / tiles_w;
+    const int ho = (int)(q % Ho), img = (int)(q / Ho);
+    const int wo = tw * 16 + lm;
+    const uint8_t* fb = frames + (size_t)img * H * W * 3;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+      const int k = 4 * s + lg, tap = k / 3, c = k - tap * 3, kh = tap / 3, kw = tap - kh * 3;
+      const int hi = 2 * ho - 1 + kh, wi = 2 * wo - 1 + kw;
+      // clamped address + select on the value: the seven byte loads issue back to back (a predicated load is a branch
+      // and a wait per tap)
+      const bool ok = k < 27 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      const int hc = min(max(hi, 0), H - 1), wc = min(max(wi, 0), W - 1), cc = min(c, 2);
+      const float raw = (float)fb[((size_t)hc * W + wc) * 3 + cc] - (cc == 0 ? 104.f : (cc == 1 ? 117.f : 123.f));
+      const float v = ok ? raw : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], v, acc, 0, 0, 0);
+    }
+    if (lg < 2 && wo < Wo) {
+      f32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = acc[e] + b4[e];
+        o[e] = v > 0.f ? v : v * w.slope;
+      }
+      *reinterpret_cast<f32x4_t*>(y + (((size_t)img * Ho + ho) * Wo + wo) * 8 + lg * 4) = o;
+    }
+  }
+}
+
+hipError_t launch_retina_stem(const uint8_t* frames, int n, int H, int W, const float* wa, const float* bias, float slope, float* y,
+                              hipStream_t s) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long ntile = (long long)n * Ho * ((Wo + 15) / 16);
+  if (ntile == 0) return hipSuccess;
+  const int blocks = (int)std::min<long long>((ntile + 3) / 4, 8192);
+  hipLaunchKernelGGL(retina_stem_kernel, dim3(blocks), dim3(256), 0, s, frames, n, H, W, Ho, Wo, RetinaStemW{wa, bias, slope}, y);
+  return hipGetLastError();
+}
+
+struct DwPwW { const float *dw, *dbias, *pw, *pbias; float dslope, pslope; };   // dw [9][CIN], pw [COUT][CIN] (BN folded)
+
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256) dwpw_kernel(const float* __restrict__ x, int n, int H, int W, int stride, int Ho, int Wo, DwPwW w,
+                                                    float* __restrict__ y) {
+  // lane group g owns the CONTIGUOUS channels [g*KS, g*KS + KS): k-step s of the pointwise GEMM pairs channel g*KS + s of
+  // every group (any consistent k permutation is a valid dot product), and a lane's depthwise inputs are vector loads
+  constexpr int KS = CIN / 4, NT = COUT / 16, VL = KS < 4 ? KS : 4, NV = KS / VL;
+  typedef float vec_t __attribute__((ext_vector_type(VL)));
+  const int lane = threadIdx.x & 63, lg = lane >> 4, lm = lane & 15;
+  float wd[9][KS], bd[KS], wp[NT][KS], bp[NT][4];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    bd[s] = w.dbias[lg * KS + s];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wd[t][s] = w.dw[t * CIN + lg * KS + s];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wp[nt][s] = w.pw[(size_t)(16 * nt + lm) * CIN + lg * KS + s];
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bp[nt][e] = w.pbias[16 * nt + 4 * lg + e];
+  const int tiles_w = (Wo + 15) >> 4;
+  const long long ntile = (long long)n * Ho * tiles_w;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
+  for (long long t = wave; t < ntile; t += nwave) {
+    const int tw = (int)(t % tiles_w);
+    const long long q = t / tiles_w;
+    const int ho = (int)(q % Ho), img = (int)(q / Ho);
+    const int wo = min(tw * 16 + lm, Wo - 1);          // tail lanes recompute the last pixel and do not store
+    const float* xb = x + (size_t)img * H * W * CIN + lg * KS;
+    // all 9 x NV loads first (clamped addresses, no predicate), then the arithmetic in dwconv3x3_kernel's order
+    vec_t in[9][NV];
+    bool ok[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int hi = ho * stride - 1 + kh, wi = wo * stride - 1 + kw;
+        ok[kh * 3 + kw] = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        const float* px = xb + ((size_t)min(max(hi, 0), H - 1) * W + min(max(wi, 0), W - 1)) * CIN;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) in[kh * 3 + kw][v] = *reinterpret_cast<const vec_t*>(px + v * VL);
+      }
+    float d[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) d[s] = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float xv = in[tp][s / VL][s % VL];
+        d[s] = ok[tp] ? d[s] + xv * wd[tp][s] : d[s];
+      }
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      float v = d[s] + bd[s];
+      v = v > 0.f ? v : v * w.dslope;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[nt][s], v, acc[nt], 0, 0, 0);
+    }
+    if (tw * 16 + lm < Wo) {
+      float* o = y + (((size_t)img * Ho + ho) * Wo + wo) * COUT + 4 * lg;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4_t r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[nt][e] + bp[nt][e];
+          r[e] = v > 0.f ? v : v * w.pslope;
+        }
+        *reinterpret_cast<f32x4_t*>(o + 16 * nt) = r;
+      }
+    }
+  }
+}
+
+bool dwpw_supported(int cin, int cout) {
+  return (cin == 8 && cout == 16) || (cin == 16 && cout == 32) || (cin == 32 && cout == 32) || (cin == 32 && cout == 64);
+}
+
+hipError_t launch_dwpw(const float* x, float* y, int n, int H, int W, int cin, int cout, int stride, const float* dw, const float* dbias,
+                       float dslope, const float* pw, const float* pbias, float pslope, hipStream_t s) {
+  const int Ho = stride == 2 ? (H - 1) / 2 + 1 : H, Wo = stride == 2 ? (W - 1) / 2 + 1 : W;
+  const long long ntile = (long long)n * Ho * ((Wo + 15) / 16);
+  if (ntile == 0) return hipSuccess;
+  const int blocks = (int)std::min<long long>((ntile + 3) / 4, 8192);
+  const DwPwW w{dw, dbias, pw, pbias, dslope, pslope};
+#define VNF_DWPW(CI, CO) hipLaunchKernelGGL((dwpw_kernel<CI, CO>), dim3(blocks), dim3(256), 0, s, x, n, H, W, stride, Ho, Wo, w, y)
+  if (cin == 8 && cout == 16) VNF_DWPW(8, 16);
+  else if (cin == 16 && cout == 32) VNF_DWPW(16, 32);
+  else if (cin == 32 && cout == 32) VNF_DWPW(32, 32);
+  else if (cin == 32 && cout == 64) VNF_DWPW(32, 64);
+  else return hipErrorInvalidValue;
+#undef VNF_DWPW
   return hipGetLastError();
 }
 

@@ -972,7 +972,12 @@ static bool bn_fold_at(WeightMap& wm, const std::string& p, int C, std::vector<f
 int build_retina_mnet(Encoder& e, WeightMap& wm, int H, int W, int head_bufs[3]) {
   e.in_size = 0;
   auto down = [](int v) { return (v + 2 - 3) / 2 + 1; };
-  int cur = e.add_buf(H, W, 4);   // input: NHWC4 (R-104, G-117, B-123, 0)
+  // VNF_RETINA_FUSE=0: the early layers as plan convolutions on an NHWC4 fp32 copy of the frames (buffer 0, written by
+  // the caller); default: conv0 straight from the u8 frames (Op::RSTEM) and dw+pw blocks in one kernel (Op::DWPW)
+  // (bit 0: stem, bit 1: dw+pw blocks)
+  static const int fuse_env = getenv("VNF_RETINA_FUSE") ? atoi(getenv("VNF_RETINA_FUSE")) : 3;
+  const bool fused = fuse_env & 1, fused_dw = fuse_env & 2;
+  int cur = e.add_buf(fused ? 1 : H, fused ? 1 : W, 4);   // input: NHWC4 (R-104, G-117, B-123, 0); a stub when fused
   int h = H, w = W;
   // conv (3x3 or 1x1) + BN + optional LeakyReLU / ReLU into (buf, channel offset)
   auto conv_bn = [&](const std::string& p, int xb, int cin, int cin_pad, int cout, int k, int stride, int ob, int ooff, int act,
@@ -998,6 +1003,26 @@ int build_retina_mnet(Encoder& e, WeightMap& wm, int H, int W, int head_bufs[3])
     for (int c = 0; c < inp; ++c)
       for (int t = 0; t < 9; ++t) w9c[(size_t)t * inp + c] = dw[(size_t)c * 9 + t] * sc[c];
     const int ho = stride == 2 ? down(h) : h, wo = stride == 2 ? down(w) : w;
+    if (fused_dw && dwpw_supported(inp, oup)) {
+      const float* pw = wm.get(p + ".3.weight", (int64_t)oup * inp);
+      std::vector<float> ps, pb;
+      if (!pw || !bn_fold_at(wm, p + ".4", oup, ps, pb)) return fail(VNF_E_MISSING, "retina: missing weight " + wm.missing);
+      std::vector<float> pwf((size_t)oup * inp);
+      for (int o = 0; o < oup; ++o)
+        for (int c = 0; c < inp; ++c) pwf[(size_t)o * inp + c] = pw[(size_t)o * inp + c] * ps[o];
+      DwPwLayer d;
+      d.name = p; d.x_buf = cur; d.o_buf = e.add_buf(ho, wo, oup); d.cin = inp; d.cout = oup; d.stride = stride; d.slope = 0.1f;
+      d.dw = (float*)e.upload(w9c.data(), w9c.size() * 4);
+      d.dbias = (float*)e.upload(sh.data(), sh.size() * 4);
+      d.pw = (float*)e.upload(pwf.data(), pwf.size() * 4);
+      d.pbias = (float*)e.upload(pb.data(), pb.size() * 4);
+      if (!d.dw || !d.dbias || !d.pw || !d.pbias) return VNF_E_HIP;
+      e.dwpws.push_back(d);
+      Op op; op.kind = Op::DWPW; op.a = (int)e.dwpws.size() - 1;
+      e.ops.push_back(op);
+      cur = d.o_buf; h = ho; w = wo;
+      return VNF_OK;
+    }
     DwLayer d;
     d.x_buf = cur; d.o_buf = e.add_buf(ho, wo, inp); d.C = inp; d.stride = stride; d.slope = 0.1f;
     d.w = (float*)e.upload(w9c.data(), w9c.size() * 4);
@@ -1027,7 +1052,27 @@ int build_retina_mnet(Encoder& e, WeightMap& wm, int H, int W, int head_bufs[3])
   {
     const int ho = down(h), wo = down(w);
     const int ob = e.add_buf(ho, wo, 8);
-    TRY(conv_bn("body.stage1.0", cur, 3, 4, 8, 3, 2, ob, 0, ACT_PRELU, 0.1f));
+    if (fused) {
+      const float* w0 = wm.get("body.stage1.0.0.weight", 8 * 27);
+      std::vector<float> sc, sh;
+      if (!w0 || !bn_fold_at(wm, "body.stage1.0.1", 8, sc, sh)) return fail(VNF_E_MISSING, "retina: missing weight " + wm.missing);
+      std::vector<float> wa(7 * 64, 0.f);
+      for (int s7 = 0; s7 < 7; ++s7)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int lg = lane >> 4, lm = lane & 15, k = 4 * s7 + lg;
+          if (lm < 8 && k < 27) {
+            const int tap = k / 3, c = k % 3;
+            wa[s7 * 64 + lane] = w0[(lm * 3 + c) * 9 + tap] * sc[lm];
+          }
+        }
+      e.rstem_wa = (float*)e.upload(wa.data(), wa.size() * 4);
+      e.rstem_bias = (float*)e.upload(sh.data(), 8 * 4);
+      if (!e.rstem_wa || !e.rstem_bias) return VNF_E_HIP;
+      Op op; op.kind = Op::RSTEM; op.a = H; op.b = ob; op.c = W;
+      e.ops.push_back(op);
+    } else {
+      TRY(conv_bn("body.stage1.0", cur, 3, 4, 8, 3, 2, ob, 0, ACT_PRELU, 0.1f));
+    }
     cur = ob; h = ho; w = wo;
   }
   TRY(conv_dw("body.stage1.1", 8, 16, 1));
@@ -1058,10 +1103,31 @@ int build_retina_mnet(Encoder& e, WeightMap& wm, int H, int W, int head_bufs[3])
   for (int l = 0; l < 3; ++l) {
     const std::string p = "ssh" + std::to_string(l + 1);
     const int cat = e.add_buf(fh[l], fw[l], 64), t5 = e.add_buf(fh[l], fw[l], 16), t7 = e.add_buf(fh[l], fw[l], 16);
-    TRY(conv_bn(p + ".conv3X3", feat_in[l], 64, 64, 32, 3, 1, cat, 0, ACT_RELU, 0.f));
-    TRY(conv_bn(p + ".conv5X5_1", feat_in[l], 64, 64, 16, 3, 1, t5, 0, ACT_PRELU, 0.1f));
-    TRY(conv_bn(p + ".conv5X5_2", t5, 16, 16, 16, 3, 1, cat, 32, ACT_RELU, 0.f));
-    TRY(conv_bn(p + ".conv7X7_2", t5, 16, 16, 16, 3, 1, t7, 0, ACT_PRELU, 0.1f));
+    // convolutions that read the same tensor run as ONE GEMM whose column ranges go to different tensors (ReLU = a
+    // PReLU slope of 0, LeakyReLU = 0.1 on the other range): conv3X3 | conv5X5_1 on the level's feature map,
+    // conv5X5_2 | conv7X7_2 on conv5X5_1's output
+    auto conv_pair = [&](const std::string& pa, int na, int ba, int oa, float sa, const std::string& pb, int nb, int bb, int ob2,
+                         float sb, int xb, int cin) -> int {
+      ConvSpec s;
+      s.name = pa + "|" + pb.substr(pb.rfind('.') + 1); s.x_buf = xb; s.cin = s.cin_pad = cin; s.KH = s.KW = 3; s.ph = s.pw = 1;
+      s.pieces.resize(2);
+      const std::string nm[2] = {pa, pb};
+      const int nn[2] = {na, nb};
+      const float sl[2] = {sa, sb};
+      for (int k = 0; k < 2; ++k) {
+        Piece& pc = s.pieces[k];
+        pc.w = wm.get(nm[k] + ".0.weight", (int64_t)nn[k] * cin * 9);
+        pc.cout = pc.cout_pad = nn[k];
+        if (!pc.w || !bn_fold_at(wm, nm[k] + ".1", nn[k], pc.scale, pc.bias)) return fail(VNF_E_MISSING, "retina: missing weight " + wm.missing);
+        pc.slope.assign(nn[k], sl[k]);
+      }
+      s.segs.push_back({0, na, ba, oa});
+      s.segs.push_back({na, na + nb, bb, ob2});
+      s.act = ACT_PRELU;
+      return add_conv(e, s);
+    };
+    TRY(conv_pair(p + ".conv3X3", 32, cat, 0, 0.f, p + ".conv5X5_1", 16, t5, 0, 0.1f, feat_in[l], 64));
+    TRY(conv_pair(p + ".conv5X5_2", 16, cat, 32, 0.f, p + ".conv7X7_2", 16, t7, 0, 0.1f, t5, 16));
     TRY(conv_bn(p + ".conv7x7_3", t7, 16, 16, 16, 3, 1, cat, 48, ACT_RELU, 0.f));
     // the three 1x1 heads of the level as one GEMM: columns [class 4 | bbox 8 | landmark 20]
     const int hb = e.add_buf(fh[l], fw[l], 32);
@@ -1304,6 +1370,22 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
                                      d.slope, s));
             break;
           }
+          case Op::RSTEM: {   // a = H, c = W of the u8 frames the caller passes as x; b = output buffer
+            if (dtype != F32 || !x) return fail(VNF_E_INVALID, "retina stem: fp32 plans on caller frames only");
+            const Buf& ob = bufs[op.b];
+            VNF_HIP(launch_retina_stem((const uint8_t*)x + (size_t)n0 * op.a * op.c * 3, nn, op.a, op.c, rstem_wa, rstem_bias, 0.1f,
+                                       (float*)ob.ptr + (size_t)n0 * ob.elems_per_image(), s));
+            break;
+          }
+          case Op::DWPW: {
+            if (dtype != F32) return fail(VNF_E_INVALID, "dw+pw: fp32 plans only");
+            const DwPwLayer& d = dwpws[op.a];
+            const Buf& ib = bufs[d.x_buf];
+            const Buf& ob = bufs[d.o_buf];
+            VNF_HIP(launch_dwpw((const float*)ib.ptr + (size_t)n0 * ib.elems_per_image(), (float*)ob.ptr + (size_t)n0 * ob.elems_per_image(),
+                                nn, ib.H, ib.W, d.cin, d.cout, d.stride, d.dw, d.dbias, d.slope, d.pw, d.pbias, d.slope, s));
+            break;
+          }
           case Op::UPADD: {
             if (dtype != F32) return fail(VNF_E_INVALID, "upsample-add: fp32 plans only");
             const Buf& ib = bufs[op.a];
@@ -1365,7 +1447,7 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
                  "3x3 s2 3->32 on the caller's tensor, VALU packed FMA", ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
       } else {
         static const char* kn[] = {"pack", "conv", "maxpool", "avgpool", "l2norm", "copyout", "maxpool_ceil", "stem1", "dwconv3x3",
-                                   "upsample_add"};
+                                   "upsample_add", "retina_stem (u8 frames -> conv0)", "dw3x3+pw1x1 fused"};
         snprintf(line, sizeof line, "%-28s %-8s %60s %8.4f ms\n", "", kn[op.kind], "", ms[oi]);
       }
       *report += line;

@@ -69,7 +69,7 @@ struct ConvLayer {
 };
 
 struct Op {
-  enum Kind { PACK, CONV, MAXPOOL, AVGPOOL, L2NORM, COPYOUT, MAXPOOLC, STEM1, DWCONV, UPADD } kind;
+  enum Kind { PACK, CONV, MAXPOOL, AVGPOOL, L2NORM, COPYOUT, MAXPOOLC, STEM1, DWCONV, UPADD, RSTEM, DWPW } kind;
   int a = 0, b = 0, c = 0, d = 0, e = 0;  // meaning per kind (see engine.cpp)
 };
 
@@ -77,6 +77,13 @@ struct DwLayer {   // depthwise 3x3 pad 1 + folded BN + LeakyReLU (fp32 plans: R
   int x_buf, o_buf, C, stride;
   float *w = nullptr, *bias = nullptr;   // [9][C], [C]
   float slope = 0.f;
+};
+
+struct DwPwLayer {   // conv_dw in one kernel (launch_dwpw): depthwise 3x3 + BN + leaky, pointwise 1x1 + BN + leaky
+  int x_buf, o_buf, cin, cout, stride;
+  float *dw = nullptr, *dbias = nullptr, *pw = nullptr, *pbias = nullptr;
+  float slope = 0.f;
+  std::string name;
 };
 
 struct Group { int first, last, chunk; };
@@ -105,6 +112,8 @@ struct Encoder : HandleBase {
   std::vector<Buf> bufs;
   std::vector<ConvLayer> convs;
   std::vector<DwLayer> dws;
+  std::vector<DwPwLayer> dwpws;
+  float *rstem_wa = nullptr, *rstem_bias = nullptr;   // RetinaFace stem (Op::RSTEM): MFMA lane table [7][64], bias [8]
   std::vector<Op> ops;
   std::vector<Group> groups;
   std::vector<FusedStack> fused;

@@ -248,13 +248,16 @@ extern "C" int vnf_retina_detect(vnf_handle h, const uint8_t* frames, int b, int
     // the activation contexts of the plan are not used here: buffer pointers are fixed after finalize()
     RetinaGeom g = r->geom;
     for (int l = 0; l < 3; ++l) g.head[l] = (const float*)e.bufs[r->head_bufs[l]].ptr;
-    const size_t npix = (size_t)b * height * width;
-    hipLaunchKernelGGL(retina_prep_kernel, dim3((unsigned)std::min<size_t>((npix + 255) / 256, 16384)), dim3(256), 0, s, frames,
-                       (float*)e.bufs[0].ptr, npix);
-    VNF_HIP(hipGetLastError());
+    const bool stem_in_plan = !e.ops.empty() && e.ops[0].kind == Op::RSTEM;   // conv0 reads the u8 frames itself
+    if (!stem_in_plan) {
+      const size_t npix = (size_t)b * height * width;
+      hipLaunchKernelGGL(retina_prep_kernel, dim3((unsigned)std::min<size_t>((npix + 255) / 256, 16384)), dim3(256), 0, s, frames,
+                         (float*)e.bufs[0].ptr, npix);
+      VNF_HIP(hipGetLastError());
+    }
     static const bool layers = getenv("VNF_RETINA_LAYERS") != nullptr;   // diagnostic: per-layer table on stderr
     std::string rep;
-    int rc = e.run(nullptr, b, VNF_F32, nullptr, s, layers ? &rep : nullptr);
+    int rc = e.run(stem_in_plan ? frames : nullptr, b, VNF_F32, nullptr, s, layers ? &rep : nullptr);
     if (rc != VNF_OK) return rc;
     if (!rep.empty()) fprintf(stderr, "%s", rep.c_str());
     VNF_HIP(hipMemsetAsync(r->cnt, 0, (2 * (size_t)r->cfg.max_batch + 8) * 4, s));
