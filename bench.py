@@ -428,7 +428,7 @@ def main():
                          "embed workload, 1 for the pipeline (measured best)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=20)   # 20 warm-up + 100 timed iterations
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f16x2", "f32"])
     ap.add_argument("--legs", default="f16x2,f16,f32",
                     help="workload all: further compute dtypes timed after the headline leg (comma list, '' for none)")
