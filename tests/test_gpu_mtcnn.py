@@ -247,3 +247,39 @@ def test_result_readback_paths_agree(monkeypatch):
         assert len(ob[i]) == len(b1[i])
         assert np.abs(np.asarray(b1[i]).reshape(-1, 4) - np.asarray(ob[i]).reshape(-1, 4)).max() <= 1e-3
         assert np.abs(np.asarray(l1[i]).reshape(-1, 10) - np.asarray(ol[i]).reshape(-1, 10)).max() <= 1e-3
+
+
+@pytest.mark.parametrize("hw,mfs,thr1", [((233, 317), 20, 0.6), ((301, 403), 30, 0.6), ((360, 641), 40, 0.5), ((487, 353), 24, 0.6)])
+def test_random_frame_sizes_match_the_oracle(hw, mfs, thr1):
+    """Odd frame sizes (rows that are not a whole number of 16-byte chunks take the per-pixel pyramid / crop paths; odd
+    level sizes exercise the ceil-mode pooling edges of the MFMA P-Net front and the R/O-Net front bands), a lowered
+    stage-1 threshold (more candidates through the sort / NMS paths), two frames per batch."""
+    from PIL import Image
+    from vn_celeb_face_recognition_amd.models import MTCNN
+    from oracle import mtcnn as om
+    h, w = hw
+    rng = np.random.default_rng(h * 1000 + w)
+    faces = [Image.fromarray(load_image(f)) for f in ("041bc30432964f95871d4c223eba8f7c.png", "318c7ec3b94b451c813a5665cfcfbda3.png",
+                                                       "33f2891da9694198a67aabd1660517c3.png")]
+    frames = []
+    for k in range(2):
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        img = np.stack([110 + 50 * np.sin(xx / w * (2 + c) + k) * np.cos(yy / h * (1.5 + c)) for c in range(3)], axis=-1)
+        img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+        for j in range(3):
+            s = int(rng.integers(48, min(h, w) // 2))
+            x0, y0 = int(rng.integers(0, w - s)), int(rng.integers(0, h - s))
+            img[y0:y0 + s, x0:x0 + s] = np.asarray(faces[(k + j) % 3].resize((s, s), Image.BICUBIC))
+        frames.append(img)
+    thr = [thr1, 0.7, 0.7]
+    det = MTCNN(keep_all=True, min_face_size=mfs, thresholds=thr, device="cuda:0", max_batch=2, max_height=h, max_width=w)
+    bb, pp, ll = det.inference(frames, landmark=True)
+    p, r, o = mtcnn_state_dicts()
+    ob, op_, ol = om.mtcnn_detect(frames, p, r, o, min_face_size=mfs, thresholds=thr, ties="table")
+    assert sum(len(b) for b in ob) >= 2
+    for i in range(2):
+        assert len(bb[i]) == len(ob[i]), (i, len(bb[i]), len(ob[i]))
+        if len(ob[i]):
+            assert np.abs(np.asarray(bb[i]) - ob[i]).max() <= 1e-3
+            assert np.abs(np.asarray(pp[i]) - op_[i]).max() <= 1e-5
+            assert np.abs(np.asarray(ll[i]) - ol[i]).max() <= 1e-3

@@ -120,3 +120,28 @@ def test_retina_errors():
     del sd["fpn.merge1.0.weight"]
     with pytest.raises(Exception, match="missing"):
         RetinaFace("cfg_mnet", device="cuda:0", state_dict=sd).inference([np.zeros((64, 64, 3), np.uint8)])
+
+
+@pytest.mark.parametrize("hw", [(233, 317), (96, 130), (401, 258)])
+def test_retina_odd_frame_sizes_match_the_oracle(hw):
+    """Odd sizes: stride-2 output sizes ceil(H/2), row tails that are not a multiple of the 16-pixel MFMA tile in the
+    stem / dw+pw kernels, nearest-neighbour upsampling between levels of unequal ratio, priors for ceil(H/step) cells."""
+    h, w = hw
+    rng = np.random.default_rng(h * 7 + w)
+    frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(2)]
+    frames[1][h // 4: h // 2, w // 4: w // 2] = 200
+    sd = generate_state_dict("retina", 0, as_torch=True)
+    from vn_celeb_face_recognition_amd.models import RetinaFace
+    det = RetinaFace("cfg_mnet", device="cuda:0", state_dict=sd, max_batch=2, vis_thres=0.3)
+    got = det.inference(frames)
+    want = oret.inference(sd, frames, ties="table", vis_thres=0.3)
+    _check_lists(got, want)
+    heads = det.debug_heads(2)
+    import torch.nn.functional as F   # noqa: F401
+    x = torch.stack([torch.from_numpy((np.float32(f) - oret.CHANNELS_SUBTRACT).transpose(2, 0, 1)) for f in frames]).float()
+    loc, cls, ldm = oret.forward(sd, x, logits=True)
+    gl = np.concatenate([hh[..., 4:12].reshape(2, -1, 4) for hh in heads], axis=1)
+    gc = np.concatenate([hh[..., 0:4].reshape(2, -1, 2) for hh in heads], axis=1)
+    assert gl.shape == tuple(loc.shape)
+    assert np.abs(gl - loc.numpy()).max() <= 2e-4 * max(1.0, float(loc.abs().max()))
+    assert np.abs(gc - cls.numpy()).max() <= 2e-4 * max(1.0, float(cls.abs().max()))
