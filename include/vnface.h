@@ -146,10 +146,12 @@ typedef struct {
   int32_t select_largest;  /* mtcnn.py:203: order boxes by area, descending */
   int32_t max_batch;       /* frames per call */
   int32_t max_height, max_width;
-  int32_t max_candidates;  /* reserved (must be 0): the candidate tables are compile-time sized -- 4096 P-Net cells
-                            * above threshold per (pyramid level, frame), 8192 per frame into the cross-scale NMS,
-                            * 2048 survivors per stage and frame; a frame that exceeds them fails the call with
-                            * VNF_E_CAPACITY (never a silent truncation) */
+  int32_t max_candidates;  /* stage-1 candidates (P-Net cells above thresholds[0]) per (pyramid level, frame): 0 = 8192
+                            * when every level has fewer than 2^19 P-Net cells (1080p at any min_face_size), else 4096;
+                            * a value in (0, 4096] selects the 4096-entry table.  The other tables are compile-time
+                            * sized: 8192 candidates per frame into the cross-scale NMS, 2048 survivors per NMS, stage and
+                            * frame.  A frame that exceeds any of them fails the call with VNF_E_CAPACITY (never a
+                            * silent truncation) */
 } vnf_mtcnn_cfg;
 
 int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const vnf_tensor_desc* rnet, int n_rnet,

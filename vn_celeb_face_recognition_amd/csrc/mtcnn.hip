@@ -37,7 +37,9 @@ namespace vnf {
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
 constexpr int MAX_LEVELS = 24;
-constexpr int CAP_SCALE = 4096;  // candidates per (level, frame) before NMS (12-bit slot in the sort key)
+constexpr int CAP_SCALE = 4096;  // candidates per (level, frame) before NMS: the default of the run-time capacity (12-bit slot in
+                                 // the sort key); 8192 (13-bit slot) when every level has fewer than 2^19 P-Net cells, vnf_mtcnn_cfg.max_candidates
+constexpr int CAP_SCALE_MAX = 8192;
 constexpr int CAP_IMG = 8192;    // candidates per frame entering the cross-scale NMS
 constexpr int KEEP = 2048;       // survivors per frame after any NMS pass (stage-2 / stage-3 table rows)
 
@@ -440,7 +442,7 @@ __global__ void pnet_conv2_kernel(const float* __restrict__ p1, LevelTable t, PN
 // mtcnn.py:44-49: conv3 16->32 + PReLU, conv4_1 (1x1 ->2) + softmax, conv4_2 (1x1 -> 4);
 // detect_face.py:209: mask = prob[:,1] >= thr, fused: survivors are appended to the
 // (level, frame) candidate list.  prob_dbg / reg_dbg (optional) receive the dense maps.
-__global__ void pnet_conv3_heads_kernel(const float* __restrict__ c2, LevelTable t, PNetW w, float thr, int B,
+__global__ void pnet_conv3_heads_kernel(const float* __restrict__ c2, LevelTable t, PNetW w, float thr, int B, int cap_scale,
                                         Cand* __restrict__ cand, int* __restrict__ cand_cnt, int* __restrict__ status,
                                         float* __restrict__ prob_dbg, float* __restrict__ reg_dbg) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -494,10 +496,10 @@ __global__ void pnet_conv3_heads_kernel(const float* __restrict__ c2, LevelTable
   if (prob >= thr) {
     const int seg = li * B + img;
     const int slot = atomicAdd(&cand_cnt[seg], 1);
-    if (slot < CAP_SCALE) {
+    if (slot < cap_scale) {
       Cand c;
       c.score = prob; c.r0 = r0; c.r1 = r1; c.r2 = r2; c.r3 = r3; c.cell = p;
-      cand[(size_t)seg * CAP_SCALE + slot] = c;
+      cand[(size_t)seg * cap_scale + slot] = c;
     } else {
       atomicOr(status, ST_OVER_SCALE);
     }
@@ -517,32 +519,34 @@ __device__ __forceinline__ float4 cell_box(int cell, int ow, float scale) {
 // score-descending over nonzero() order (y, x): key = (inverted score | cell | slot).
 __global__ void __launch_bounds__(256) nms_scale_kernel(const Cand* __restrict__ cand, const int* __restrict__ cand_cnt,
                                                          LevelTable t, int B, float thr, Cand* __restrict__ keep,
-                                                         int* __restrict__ keep_cnt, int* __restrict__ status) {
+                                                         int* __restrict__ keep_cnt, int* __restrict__ status, int cap_scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);           // CAP_SCALE * 8
-  float4* s_kbox = reinterpret_cast<float4*>(smem + CAP_SCALE * 8);                  // KEEP * 16
-  int* s_keep = reinterpret_cast<int*>(smem + CAP_SCALE * 8 + KEEP * 16);            // KEEP * 4
-  float4* s_cbox = reinterpret_cast<float4*>(smem + CAP_SCALE * 8 + KEEP * 20);      // 256 * 16
-  int* s_alive = reinterpret_cast<int*>(smem + CAP_SCALE * 8 + KEEP * 20 + 256 * 16);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);           // cap_scale * 8
+  float4* s_kbox = reinterpret_cast<float4*>(smem + cap_scale * 8);                  // KEEP * 16
+  int* s_keep = reinterpret_cast<int*>(smem + cap_scale * 8 + KEEP * 16);            // KEEP * 4
+  float4* s_cbox = reinterpret_cast<float4*>(smem + cap_scale * 8 + KEEP * 20);      // 256 * 16
+  int* s_alive = reinterpret_cast<int*>(smem + cap_scale * 8 + KEEP * 20 + 256 * 16);
   const int li = blockIdx.x, img = blockIdx.y, seg = li * B + img;
-  const int n = min(cand_cnt[seg], CAP_SCALE);
+  const int sbits = cap_scale > 4096 ? 13 : 12;                                      // slot bits of the key (cell < 2^(32 - sbits))
+  const unsigned smask = (1u << sbits) - 1u;
+  const int n = min(cand_cnt[seg], cap_scale);
   if (n == 0) {
     if (threadIdx.x == 0) keep_cnt[seg] = 0;
     return;
   }
-  const Cand* c = cand + (size_t)seg * CAP_SCALE;
+  const Cand* c = cand + (size_t)seg * cap_scale;
   const int npad = next_pow2(n);
   for (int i = threadIdx.x; i < npad; i += blockDim.x)
-    keys[i] = i < n ? ((unsigned long long)inv_score_bits(c[i].score) << 32) | ((unsigned long long)(unsigned)c[i].cell << 12) | (unsigned)i
+    keys[i] = i < n ? ((unsigned long long)inv_score_bits(c[i].score) << 32) | ((unsigned long long)(unsigned)c[i].cell << sbits) | (unsigned)i
                     : ~0ull;
   __syncthreads();
   block_sort(keys, n, npad);
   const int ow = t.l[li].ow;
   const float scale = t.l[li].scale;
-  auto getbox = [&](int r) { return cell_box(c[(int)(keys[r] & 0xFFF)].cell, ow, scale); };
+  auto getbox = [&](int r) { return cell_box(c[(int)(keys[r] & smask)].cell, ow, scale); };
   const int nk = block_greedy_nms<NMS_TV>(n, thr, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
   Cand* o = keep + (size_t)seg * KEEP;
-  for (int k = threadIdx.x; k < nk; k += blockDim.x) o[k] = c[(int)(keys[s_keep[k]] & 0xFFF)];
+  for (int k = threadIdx.x; k < nk; k += blockDim.x) o[k] = c[(int)(keys[s_keep[k]] & smask)];
   if (threadIdx.x == 0) keep_cnt[seg] = nk;
 }
 
@@ -1400,6 +1404,7 @@ struct Mtcnn : HandleBase {
   float *crops = nullptr, *rout = nullptr, *oout = nullptr, *fin = nullptr;
   float *prob_dbg = nullptr, *reg_dbg = nullptr;
   Encoder *renc = nullptr, *oenc = nullptr;  // R-Net / O-Net plans on the exact-f32 MFMA core (candidates = batch)
+  int cap_scale = CAP_SCALE;                  // stage-1 candidates per (level, frame): 4096 or 8192 (see vnf_mtcnn_create)
   int pnet1_lds = 0;                          // dynamic LDS granted to pnet_conv1_pool_mfma_kernel
   bool front = false;                         // conv1 + PReLU + pool1 of both nets by net_front_kernel (plans start at conv2)
   FrontW rfw{}, ofw{};
@@ -1600,7 +1605,16 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
     m->p1 = (float*)m->dalloc(m->cap_p1 * 10 * B * 4);
     m->c2 = (float*)m->dalloc(m->cap_c2 * 16 * B * 4);
     const size_t nseg = (size_t)MAX_LEVELS * B;
-    m->cand = (Cand*)m->dalloc(nseg * CAP_SCALE * sizeof(Cand));
+    {
+      // per-(level, frame) capacity of the stage-1 candidate table: 8192 when the 13-bit slot leaves room for every
+      // level's cell index (cells < 2^19: up to ~2.5 Mpx at min_face_size 12, 1080p at any), else 4096;
+      // cfg.max_candidates in (0, 4096] keeps the smaller table
+      long long max_cells = 0;
+      for (int l = 0; l < m->cap_table.n; ++l) max_cells = std::max(max_cells, (long long)m->cap_table.l[l].oh * m->cap_table.l[l].ow);
+      const bool want_small = cfg->max_candidates > 0 && cfg->max_candidates <= CAP_SCALE;
+      m->cap_scale = (!want_small && max_cells * 1.1 < (double)(1 << 19)) ? CAP_SCALE_MAX : CAP_SCALE;
+    }
+    m->cand = (Cand*)m->dalloc(nseg * m->cap_scale * sizeof(Cand));
     m->keep1 = (Cand*)m->dalloc(nseg * KEEP * sizeof(Cand));
     m->cand_cnt = (int*)m->dalloc((nseg * 2 + (size_t)B * 3 + 16) * 4);
     m->keep1_cnt = m->cand_cnt + nseg;
@@ -1632,7 +1646,7 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
     {
       int lds_max = 0;
       VNF_HIP(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, m->device));
-      const int need_img = CAP_IMG * 8 + KEEP * 20 + 256 * 20, need_scale = CAP_SCALE * 8 + KEEP * 20 + 256 * 20;
+      const int need_img = CAP_IMG * 8 + KEEP * 20 + 256 * 20, need_scale = CAP_SCALE_MAX * 8 + KEEP * 20 + 256 * 20;   // per function, not per handle: the larger table
       const int need_post = KEEP * 44 + 256 * 20, need_r = (13552 + 3388 + 864) * 4, need_o = (16928 + 14112 + 6912 + 1152) * 4;
       (void)hipFuncSetAttribute((const void*)nms_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_img);
       {
@@ -1691,7 +1705,8 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   if ((size_t)t.tot_px > m->cap_px || (size_t)t.tot_p1 > m->cap_p1 || (size_t)t.tot_c2 > m->cap_c2 || (size_t)t.tot_out > m->cap_out)
     return fail(VNF_E_CAPACITY, "mtcnn: pyramid exceeds handle capacity");
   for (int l = 0; l < t.n; ++l)
-    if ((long long)t.l[l].oh * t.l[l].ow >= (1 << 20)) return fail(VNF_E_CAPACITY, "mtcnn: level too large for the 20-bit cell index");
+    if ((long long)t.l[l].oh * t.l[l].ow >= (m->cap_scale > CAP_SCALE ? (1 << 19) : (1 << 20)))
+      return fail(VNF_E_CAPACITY, "mtcnn: level too large for the cell index of the sort key");
   const int B = b;
   const size_t nseg = (size_t)MAX_LEVELS * cfg.max_batch;
   VNF_HIP(hipMemsetAsync(m->cand_cnt, 0, (nseg * 2 + (size_t)cfg.max_batch * 3 + 16) * 4, s));
@@ -1726,12 +1741,12 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   hipLaunchKernelGGL(pnet_conv2_kernel, dim3((t.tot_c2 + 255) / 256, B), dim3(256), 0, s, m->p1, t, m->pw, m->c2);
   mark("pnet_conv2", fB * ((double)t.tot_p1 * 40 + (double)t.tot_c2 * 64));
   hipLaunchKernelGGL(pnet_conv3_heads_kernel, dim3((t.tot_out + 255) / 256, B), dim3(256), 0, s, m->c2, t, m->pw,
-                     cfg.thresholds[0], B, m->cand, m->cand_cnt, m->status, m->prob_dbg, m->reg_dbg);
+                     cfg.thresholds[0], B, m->cap_scale, m->cand, m->cand_cnt, m->status, m->prob_dbg, m->reg_dbg);
   mark("pnet_conv3_heads", fB * (double)t.tot_c2 * 64);
-  const size_t lds_scale = (size_t)CAP_SCALE * 8 + KEEP * 20 + 256 * 20;
+  const size_t lds_scale = (size_t)m->cap_scale * 8 + KEEP * 20 + 256 * 20;
   const size_t lds_img = (size_t)CAP_IMG * 8 + KEEP * 20 + 256 * 20;
   hipLaunchKernelGGL(nms_scale_kernel, dim3(t.n, B), dim3(256), lds_scale, s, m->cand, m->cand_cnt, t, B, 0.5f, m->keep1,
-                     m->keep1_cnt, m->status);
+                     m->keep1_cnt, m->status, m->cap_scale);
   hipLaunchKernelGGL(nms_image_kernel, dim3(B), dim3(256), lds_img, s, m->keep1, m->keep1_cnt, t, B, 0.7f, W, H, m->rows,
                      m->row_cnt, m->status);
   VNF_HIP(hipGetLastError());

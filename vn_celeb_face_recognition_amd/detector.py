@@ -29,7 +29,7 @@ def _load_net(name):
 class MTCNN:
     def __init__(self, image_size=160, margin=0, min_face_size=20, thresholds=[0.6, 0.7, 0.7], factor=0.709,
                  post_process=True, select_largest=True, selection_method=None, keep_all=False, device=None,
-                 max_batch=16, max_height=1080, max_width=1920, state_dicts=None):
+                 max_batch=16, max_height=1080, max_width=1920, state_dicts=None, max_candidates=0):
         self.image_size = image_size
         self.margin = margin
         self.min_face_size = int(min_face_size)
@@ -42,6 +42,7 @@ class MTCNN:
         self.training = False
         self._sd = state_dicts or tuple(_load_net(n) for n in ("pnet", "rnet", "onet"))
         self._cap = [int(max_batch), int(max_height), int(max_width)]
+        self._max_candidates = int(max_candidates)    # vnf_mtcnn_cfg.max_candidates (0: the library's default table size)
         self._handle = None
         self._handle_key = None
         self._frames = None
@@ -86,7 +87,7 @@ class MTCNN:
             cfg.factor = self.factor
             cfg.select_largest = 1 if self.select_largest else 0
             cfg.max_batch, cfg.max_height, cfg.max_width = self._cap
-            cfg.max_candidates = 0
+            cfg.max_candidates = self._max_candidates
             (dp, np_, kp), (dr, nr, kr), (do, no, ko) = (_lib.make_descs(sd) for sd in self._sd)
             h_ = ctypes.c_void_p()
             _lib.check(lib.vnf_mtcnn_create(dp, np_, dr, nr, do, no, ctypes.byref(cfg), ctypes.byref(h_)))
