@@ -99,6 +99,14 @@ def cpu_baseline_pipeline(frames, template_size=160, n_frames=32, budget_s=12.0)
             "sample": "%d of the synthetic 1080p frames (%d faces), oracle detect+align+embed+classify, %.1f s" % (n_frames, faces, dt)}
 
 
+def make_detector(args, models, dev, nf, per):
+    """--detector mtcnn (the reference's default, cfg/detection/mtcnn.json) | retina (RetinaFace mobilenet0.25 with the
+    generator's synthetic weights: keep_top_k = the pasted faces per frame, so the stages after it see the same load)."""
+    if args.detector == "retina":
+        return models.RetinaFace("cfg_mnet", device=dev, max_batch=nf, keep_top_k=per, vis_thres=0.0)   # exact-f32 plan (default)
+    return models.MTCNN(keep_all=True, min_face_size=50, device=dev, max_batch=nf, max_height=1080, max_width=1920)
+
+
 def run_detect(args):
     """--workload detect: SURVEY.md 8(d) config 3 -- MTCNN detect + 5-point alignment only, synthetic 1080p frames,
     16 frames per step, frames resident in HBM; roofline = HBM on the stage-1 algorithmic bytes (a lower bound for
@@ -117,8 +125,7 @@ def run_detect(args):
     NF, PER, NT = 16, 8, max(1, args.detectors)
     frames, _ = make_frames(NF * 2, PER, seed=0)
     batches = [torch.from_numpy(frames[i * NF:(i + 1) * NF]).to(dev) for i in range(2)]
-    dets = [models.MTCNN(keep_all=True, min_face_size=50, device=dev, max_batch=NF, max_height=1080, max_width=1920)
-            for _ in range(NT)]
+    dets = [make_detector(args, models, dev, NF, PER) for _ in range(NT)]
     tmpl = center_point_dict["(160, 160)"]
     faces = [0] * NT
 
@@ -153,11 +160,14 @@ def run_detect(args):
     stage1_bytes = 13_316_400.0 * NF
     achieved = stage1_bytes * args.steps / wall / 1e9
     print(json.dumps({
-        "metric": "frames/sec MTCNN detect+align on 1080p frames (SURVEY 8d config 3)", "value": round(NF * args.steps / wall, 1),
+        "metric": "frames/sec %s detect+align on 1080p frames (SURVEY 8d config 3)" % ("MTCNN" if args.detector == "mtcnn" else "RetinaFace"),
+        "value": round(NF * args.steps / wall, 1),
         "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "MTCNN P/R/O cascade + 5-point warp, synthetic 1080p frames, %d frames/step, %d pasted "
-                               "faces/frame, min_face_size 50, %d detector handle(s)/thread(s)" % (NF, PER, NT),
+        "config": {"workload": "%s + 5-point warp, synthetic 1080p frames, %d frames/step, %d pasted "
+                               "faces/frame, %d detector handle(s)/thread(s)" % (
+                                   "MTCNN P/R/O cascade (min_face_size 50)" if args.detector == "mtcnn" else
+                                   "RetinaFace mobilenet0.25 (synthetic weights, keep_top_k 8)", NF, PER, NT),
                    "faces_per_s": round(sum(faces) / wall, 1)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 5), "traffic": None,
@@ -177,8 +187,7 @@ def pipeline_leg(args, rank, world, local, steps, warmup, lanes, want_cpu):
     frames, truth = make_frames(NF * 2, PER, seed=rank)
     # two detector handles: each gets a host thread and a HIP stream, so one batch's detection runs under the
     # other's host synchronisations (FacePipeline.submit)
-    det = [models.MTCNN(keep_all=True, min_face_size=50, device=dev, max_batch=NF, max_height=1080, max_width=1920)
-           for _ in range(args.detectors)]
+    det = [make_detector(args, models, dev, NF, PER) for _ in range(args.detectors)]
     enc = models.InceptionResnetV1(pretrained=None, compute_dtype=args.dtype, max_batch=max(256, args.embed_batch)).to(dev).eval()
     clf = models.MLPModel(512, 1001).to(dev).eval()
     pipe = FacePipeline(det, enc, clf, {"label": list(range(1001)), "name": ["c%d" % i for i in range(1001)]}, 160, 0.0,
@@ -227,14 +236,15 @@ def pipeline_leg(args, rank, world, local, steps, warmup, lanes, want_cpu):
     if world > 1:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); wall = float(mx[0])
         dist.all_reduce(tot); faces = int(tot[1].item())
-    stage_ms = det[0].stage_times(batches[0]) if rank == 0 else None
+    stage_ms = det[0].stage_times(batches[0]) if rank == 0 and hasattr(det[0], "stage_times") else None
     out = None
     if rank == 0:
         out = {"metric": "faces/sec end-to-end (detect+embed+classify) on 1080p frames", "value": round(faces / wall, 1),
                "unit": "faces/s", "n_gpus": world, "steps": steps, "warmup": warmup,
                "ms_per_step": round(wall * 1e3 / steps, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": "BASELINE.json configs[2]+[3]: MTCNN detect + align + IRv1 embed + MLP classify, "
+               "config": {"workload": "BASELINE.json configs[2]+[3]: " + ("MTCNN" if args.detector == "mtcnn" else "RetinaFace (synthetic weights)") +
+                                      " detect + align + IRv1 embed + MLP classify, "
                                       "synthetic 1080p frames, %d frames/step/GPU, %d pasted faces/frame; detection and embedding on "
                                       "separate streams, faces embedded in groups of >= %d" % (NF, PER, args.embed_batch),
                           "frames_per_s": round(world * NF * steps / wall, 1), "min_face_size": 50},
@@ -421,6 +431,7 @@ def main():
     ap.add_argument("--embed-batch", type=int, default=256,
                     help="pipeline workload: faces of consecutive frame batches are embedded together once this many wait "
                          "(0: every frame batch on its own)")
+    ap.add_argument("--detector", default="mtcnn", choices=["mtcnn", "retina"], help="detect / pipeline workloads: the detector plugin")
     ap.add_argument("--detectors", type=int, default=1, help="pipeline workload: detector handles (host threads) per GPU")
     ap.add_argument("--lanes", type=int, default=0,
                     help="streams / encoder activation contexts that consecutive embed launches rotate over (1: one stream; the "

@@ -145,3 +145,21 @@ def test_retina_odd_frame_sizes_match_the_oracle(hw):
     assert gl.shape == tuple(loc.shape)
     assert np.abs(gl - loc.numpy()).max() <= 2e-4 * max(1.0, float(loc.abs().max()))
     assert np.abs(gc - cls.numpy()).max() <= 2e-4 * max(1.0, float(cls.abs().max()))
+
+
+def test_retina_split_f16_plan_matches_the_reference_golden():
+    """compute_dtype='f16x2' (split-f16 storage and products, conv0 / depthwise arithmetic in fp32): same detection lists,
+    scores within 5e-5 of the reference's fp32 run, coordinates within 2e-2 px."""
+    from vn_celeb_face_recognition_amd.models import RetinaFace
+    g = np.load(os.path.join(GOLDEN, "retina_ref.npz"))
+    frames = _frames()
+    det = RetinaFace("cfg_mnet", device="cuda:0", max_batch=2, compute_dtype="f16x2")
+    got = det.inference(list(frames))
+    want = tuple([g["synth/%d/%s" % (i, k)] for i in range(2)] for k in ("boxes", "scores", "points"))
+    for i in range(2):
+        assert len(got[1][i]) == len(want[1][i])
+        assert np.abs(got[1][i] - want[1][i]).max() <= 5e-5
+        assert np.abs(got[0][i] - want[0][i]).max() <= 2e-2
+        assert np.abs(got[2][i].reshape(-1, 5, 2) - want[2][i]).max() <= 2e-2
+    with pytest.raises(ValueError):
+        RetinaFace("cfg_mnet", compute_dtype="bf16")

@@ -30,7 +30,7 @@ class MtcnnCfg(ctypes.Structure):
 class RetinaCfg(ctypes.Structure):
     _fields_ = [("height", ctypes.c_int32), ("width", ctypes.c_int32), ("max_batch", ctypes.c_int32),
                 ("conf_thres", ctypes.c_float), ("topk_bf_nms", ctypes.c_int32), ("nms_thres", ctypes.c_float),
-                ("keep_top_k", ctypes.c_int32), ("vis_thres", ctypes.c_float)]
+                ("keep_top_k", ctypes.c_int32), ("vis_thres", ctypes.c_float), ("compute_dtype", ctypes.c_int32)]
 
 
 _lib = None

@@ -323,6 +323,11 @@ hipError_t launch_logsoftmax_argmax(const float* logits, int ld, int C, int n, f
 // ---------------------------------------------------------------- depthwise 3x3 (MobileNetV1 blocks of RetinaFace)
 // HBM-bound: one thread per (pixel, 4 channels), nine 16-byte loads, taps in (kh, kw) order as the reference's
 // grouped conv sums them
+// SPLIT: the tensor holds split-f16 (hi, lo) pairs in its 32-bit elements (the F16X2 plans) instead of fp32
+template <bool SPLIT> __device__ __forceinline__ float ldv(float raw) { return SPLIT ? (float)__builtin_bit_cast(sf16, raw) : raw; }
+template <bool SPLIT> __device__ __forceinline__ float stv(float v) { return SPLIT ? __builtin_bit_cast(float, sf16(v)) : v; }
+
+template <bool SPLIT>
 __global__ void dwconv3x3_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int H, int W, int C, int stride,
                                  int Ho, int Wo, const float* __restrict__ w9c, const float* __restrict__ bias, float slope) {
   const int c4 = C >> 2;
@@ -344,7 +349,7 @@ __global__ void dwconv3x3_kernel(const float* __restrict__ x, float* __restrict_
           const f32x4_t v = *reinterpret_cast<const f32x4_t*>(x + ((img * H + hi) * W + wi) * C + c);
           const f32x4_t ww = *reinterpret_cast<const f32x4_t*>(w9c + (kh * 3 + kw) * C + c);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] = acc[e] + v[e] * ww[e];
+          for (int e = 0; e < 4; ++e) acc[e] = acc[e] + ldv<SPLIT>(v[e]) * ww[e];
         }
       }
     const f32x4_t b = *reinterpret_cast<const f32x4_t*>(bias + c);
@@ -352,20 +357,21 @@ __global__ void dwconv3x3_kernel(const float* __restrict__ x, float* __restrict_
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float v = acc[e] + b[e];
-      o[e] = v > 0.f ? v : v * slope;
+      o[e] = stv<SPLIT>(v > 0.f ? v : v * slope);
     }
     *reinterpret_cast<f32x4_t*>(y + p * C + c) = o;
   }
 }
 
 hipError_t launch_dwconv3x3(const float* x, float* y, int n, int H, int W, int C, int stride, const float* w9c,
-                            const float* bias, float slope, hipStream_t s) {
+                            const float* bias, float slope, bool split, hipStream_t s) {
   if (C % 4 || (stride != 1 && stride != 2)) return hipErrorInvalidValue;
   const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   const size_t total = (size_t)n * Ho * Wo * (C / 4);
   if (total == 0) return hipSuccess;
   const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(blocks), dim3(256), 0, s, x, y, n, H, W, C, stride, Ho, Wo, w9c, bias, slope);
+  if (split) hipLaunchKernelGGL(dwconv3x3_kernel<true>, dim3(blocks), dim3(256), 0, s, x, y, n, H, W, C, stride, Ho, Wo, w9c, bias, slope);
+  else hipLaunchKernelGGL(dwconv3x3_kernel<false>, dim3(blocks), dim3(256), 0, s, x, y, n, H, W, C, stride, Ho, Wo, w9c, bias, slope);
   return hipGetLastError();
 }
 
@@ -384,6 +390,7 @@ hipError_t launch_dwconv3x3(const float* x, float* y, int n, int H, int W, int C
 //     never reaches memory.  Depthwise arithmetic (mul, add, tap order) is that of dwconv3x3_kernel.
 struct RetinaStemW { const float* wa; const float* bias; float slope; };   // wa: [7][64] lane table, bias[8]
 
+template <bool SPLIT>
 __global__ void __launch_bounds__(256) retina_stem_kernel(const uint8_t* __restrict__ frames, int n, int H, int W, int Ho, int Wo,
                                                            RetinaStemW w, float* __restrict__ y) {
   // (tried and slower: four tiles in flight per wave, 0.15 ms per 8 frames; rows staged as aligned dwords in a
@@ -422,7 +429,7 @@ __global__ void __launch_bounds__(256) retina_stem_kernel(const uint8_t* __restr
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float v = acc[e] + b4[e];
-        o[e] = v > 0.f ? v : v * w.slope;
+        o[e] = stv<SPLIT>(v > 0.f ? v : v * w.slope);
       }
       *reinterpret_cast<f32x4_t*>(y + (((size_t)img * Ho + ho) * Wo + wo) * 8 + lg * 4) = o;
     }
@@ -430,18 +437,19 @@ __global__ void __launch_bounds__(256) retina_stem_kernel(const uint8_t* __restr
 }
 
 hipError_t launch_retina_stem(const uint8_t* frames, int n, int H, int W, const float* wa, const float* bias, float slope, float* y,
-                              hipStream_t s) {
+                              bool split, hipStream_t s) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long long ntile = (long long)n * Ho * ((Wo + 15) / 16);
   if (ntile == 0) return hipSuccess;
   const int blocks = (int)std::min<long long>((ntile + 3) / 4, 8192);
-  hipLaunchKernelGGL(retina_stem_kernel, dim3(blocks), dim3(256), 0, s, frames, n, H, W, Ho, Wo, RetinaStemW{wa, bias, slope}, y);
+  if (split) hipLaunchKernelGGL(retina_stem_kernel<true>, dim3(blocks), dim3(256), 0, s, frames, n, H, W, Ho, Wo, RetinaStemW{wa, bias, slope}, y);
+  else hipLaunchKernelGGL(retina_stem_kernel<false>, dim3(blocks), dim3(256), 0, s, frames, n, H, W, Ho, Wo, RetinaStemW{wa, bias, slope}, y);
   return hipGetLastError();
 }
 
 struct DwPwW { const float *dw, *dbias, *pw, *pbias; float dslope, pslope; };   // dw [9][CIN], pw [COUT][CIN] (BN folded)
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool SPLIT>
 __global__ void __launch_bounds__(256) dwpw_kernel(const float* __restrict__ x, int n, int H, int W, int stride, int Ho, int Wo, DwPwW w,
                                                     float* __restrict__ y) {
   // lane group g owns the CONTIGUOUS channels [g*KS, g*KS + KS): k-step s of the pointwise GEMM pairs channel g*KS + s of
@@ -491,7 +499,7 @@ __global__ void __launch_bounds__(256) dwpw_kernel(const float* __restrict__ x, 
     for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const float xv = in[tp][s / VL][s % VL];
+        const float xv = ldv<SPLIT>(in[tp][s / VL][s % VL]);
         d[s] = ok[tp] ? d[s] + xv * wd[tp][s] : d[s];
       }
     f32x4_t acc[NT];
@@ -512,7 +520,7 @@ __global__ void __launch_bounds__(256) dwpw_kernel(const float* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = acc[nt][e] + bp[nt][e];
-          r[e] = v > 0.f ? v : v * w.pslope;
+          r[e] = stv<SPLIT>(v > 0.f ? v : v * w.pslope);
         }
         *reinterpret_cast<f32x4_t*>(o + 16 * nt) = r;
       }
@@ -525,13 +533,17 @@ bool dwpw_supported(int cin, int cout) {
 }
 
 hipError_t launch_dwpw(const float* x, float* y, int n, int H, int W, int cin, int cout, int stride, const float* dw, const float* dbias,
-                       float dslope, const float* pw, const float* pbias, float pslope, hipStream_t s) {
+                       float dslope, const float* pw, const float* pbias, float pslope, bool split, hipStream_t s) {
   const int Ho = stride == 2 ? (H - 1) / 2 + 1 : H, Wo = stride == 2 ? (W - 1) / 2 + 1 : W;
   const long long ntile = (long long)n * Ho * ((Wo + 15) / 16);
   if (ntile == 0) return hipSuccess;
   const int blocks = (int)std::min<long long>((ntile + 3) / 4, 8192);
   const DwPwW w{dw, dbias, pw, pbias, dslope, pslope};
-#define VNF_DWPW(CI, CO) hipLaunchKernelGGL((dwpw_kernel<CI, CO>), dim3(blocks), dim3(256), 0, s, x, n, H, W, stride, Ho, Wo, w, y)
+#define VNF_DWPW(CI, CO)                                                                                                    \
+  do {                                                                                                                      \
+    if (split) hipLaunchKernelGGL((dwpw_kernel<CI, CO, true>), dim3(blocks), dim3(256), 0, s, x, n, H, W, stride, Ho, Wo, w, y); \
+    else hipLaunchKernelGGL((dwpw_kernel<CI, CO, false>), dim3(blocks), dim3(256), 0, s, x, n, H, W, stride, Ho, Wo, w, y);      \
+  } while (0)
   if (cin == 8 && cout == 16) VNF_DWPW(8, 16);
   else if (cin == 16 && cout == 32) VNF_DWPW(16, 32);
   else if (cin == 32 && cout == 32) VNF_DWPW(32, 32);
@@ -541,6 +553,7 @@ hipError_t launch_dwpw(const float* x, float* y, int n, int H, int W, int cin, i
   return hipGetLastError();
 }
 
+template <bool SPLIT>
 __global__ void upsample_add_kernel(const float* __restrict__ x, int Hs, int Ws, float* __restrict__ y, int H, int W, int C,
                                     int n, float sh, float sw) {
   const int c4 = C >> 2;
@@ -558,18 +571,22 @@ __global__ void upsample_add_kernel(const float* __restrict__ x, int Hs, int Ws,
     const f32x4_t b = *reinterpret_cast<const f32x4_t*>(x + ((img * Hs + hs) * Ws + ws) * C + c);
     f32x4_t o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = a[e] + b[e];
+    for (int e = 0; e < 4; ++e) o[e] = stv<SPLIT>(ldv<SPLIT>(a[e]) + ldv<SPLIT>(b[e]));
     *reinterpret_cast<f32x4_t*>(y + p * C + c) = o;
   }
 }
 
-hipError_t launch_upsample_add(const float* x, int Hs, int Ws, float* y, int H, int W, int C, int n, hipStream_t s) {
+hipError_t launch_upsample_add(const float* x, int Hs, int Ws, float* y, int H, int W, int C, int n, bool split, hipStream_t s) {
   if (C % 4) return hipErrorInvalidValue;
   const size_t total = (size_t)n * H * W * (C / 4);
   if (total == 0) return hipSuccess;
   const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  hipLaunchKernelGGL(upsample_add_kernel, dim3(blocks), dim3(256), 0, s, x, Hs, Ws, y, H, W, C, n, (float)Hs / (float)H,
-                     (float)Ws / (float)W);
+  if (split)
+    hipLaunchKernelGGL(upsample_add_kernel<true>, dim3(blocks), dim3(256), 0, s, x, Hs, Ws, y, H, W, C, n, (float)Hs / (float)H,
+                       (float)Ws / (float)W);
+  else
+    hipLaunchKernelGGL(upsample_add_kernel<false>, dim3(blocks), dim3(256), 0, s, x, Hs, Ws, y, H, W, C, n, (float)Hs / (float)H,
+                       (float)Ws / (float)W);
   return hipGetLastError();
 }
 

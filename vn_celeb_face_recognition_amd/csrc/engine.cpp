@@ -1361,37 +1361,37 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
             break;
           }
           case Op::DWCONV: {
-            if (dtype != F32) return fail(VNF_E_INVALID, "depthwise conv: fp32 plans only");
+            if (dtype != F32 && dtype != F16X2) return fail(VNF_E_INVALID, "depthwise conv: fp32 / split-f16 plans only");
             const DwLayer& d = dws[op.a];
             const Buf& ib = bufs[d.x_buf];
             const Buf& ob = bufs[d.o_buf];
             VNF_HIP(launch_dwconv3x3((const float*)ib.ptr + (size_t)n0 * ib.elems_per_image(),
                                      (float*)ob.ptr + (size_t)n0 * ob.elems_per_image(), nn, ib.H, ib.W, d.C, d.stride, d.w, d.bias,
-                                     d.slope, s));
+                                     d.slope, dtype == F16X2, s));
             break;
           }
           case Op::RSTEM: {   // a = H, c = W of the u8 frames the caller passes as x; b = output buffer
-            if (dtype != F32 || !x) return fail(VNF_E_INVALID, "retina stem: fp32 plans on caller frames only");
+            if ((dtype != F32 && dtype != F16X2) || !x) return fail(VNF_E_INVALID, "retina stem: fp32 / split-f16 plans on caller frames only");
             const Buf& ob = bufs[op.b];
             VNF_HIP(launch_retina_stem((const uint8_t*)x + (size_t)n0 * op.a * op.c * 3, nn, op.a, op.c, rstem_wa, rstem_bias, 0.1f,
-                                       (float*)ob.ptr + (size_t)n0 * ob.elems_per_image(), s));
+                                       (float*)ob.ptr + (size_t)n0 * ob.elems_per_image(), dtype == F16X2, s));
             break;
           }
           case Op::DWPW: {
-            if (dtype != F32) return fail(VNF_E_INVALID, "dw+pw: fp32 plans only");
+            if (dtype != F32 && dtype != F16X2) return fail(VNF_E_INVALID, "dw+pw: fp32 / split-f16 plans only");
             const DwPwLayer& d = dwpws[op.a];
             const Buf& ib = bufs[d.x_buf];
             const Buf& ob = bufs[d.o_buf];
             VNF_HIP(launch_dwpw((const float*)ib.ptr + (size_t)n0 * ib.elems_per_image(), (float*)ob.ptr + (size_t)n0 * ob.elems_per_image(),
-                                nn, ib.H, ib.W, d.cin, d.cout, d.stride, d.dw, d.dbias, d.slope, d.pw, d.pbias, d.slope, s));
+                                nn, ib.H, ib.W, d.cin, d.cout, d.stride, d.dw, d.dbias, d.slope, d.pw, d.pbias, d.slope, dtype == F16X2, s));
             break;
           }
           case Op::UPADD: {
-            if (dtype != F32) return fail(VNF_E_INVALID, "upsample-add: fp32 plans only");
+            if (dtype != F32 && dtype != F16X2) return fail(VNF_E_INVALID, "upsample-add: fp32 / split-f16 plans only");
             const Buf& ib = bufs[op.a];
             const Buf& ob = bufs[op.b];
             VNF_HIP(launch_upsample_add((const float*)ib.ptr + (size_t)n0 * ib.elems_per_image(), ib.H, ib.W,
-                                        (float*)ob.ptr + (size_t)n0 * ob.elems_per_image(), ob.H, ob.W, ob.C, nn, s));
+                                        (float*)ob.ptr + (size_t)n0 * ob.elems_per_image(), ob.H, ob.W, ob.C, nn, dtype == F16X2, s));
             break;
           }
           case Op::COPYOUT:

@@ -76,22 +76,24 @@ hipError_t launch_logsoftmax_argmax(const float* logits, int ld, int C, int n, f
 
 // depthwise 3x3 convolution, padding 1, stride 1 or 2, fp32 NHWC (C % 4 == 0): y = leaky(sum_t x[tap t] * w[t][c] + bias[c])
 // (retina_face_utils/components.py:30-40 conv_dw, first half; BatchNorm folded into w / bias)
+// (split: the tensors hold split-f16 pairs in their 32-bit elements -- F16X2 plans -- instead of fp32; same for the
+// three launchers below)
 hipError_t launch_dwconv3x3(const float* x, float* y, int n, int H, int W, int C, int stride, const float* w9c,
-                            const float* bias, float slope, hipStream_t s);
+                            const float* bias, float slope, bool split, hipStream_t s);
 
 // RetinaFace stem: u8 RGB frames (n,H,W,3) -> (x - (104,117,123)) -> 3x3 stride-2 pad-1 conv 3->8 + folded BN + LeakyReLU,
 // NHWC8 fp32 out (retina_face.py:158-164 + components.py:103 conv_bn(3, 8, 2)); wa = [7][64] MFMA lane table
 hipError_t launch_retina_stem(const uint8_t* frames, int n, int H, int W, const float* wa, const float* bias, float slope, float* y,
-                              hipStream_t s);
+                              bool split, hipStream_t s);
 // conv_dw in one pass (components.py:30-40): depthwise 3x3 pad 1 (stride 1|2) + BN + LeakyReLU + pointwise 1x1 + BN +
 // LeakyReLU, fp32 NHWC; (cin, cout) in {(8,16), (16,32), (32,32), (32,64)}
 bool dwpw_supported(int cin, int cout);
 hipError_t launch_dwpw(const float* x, float* y, int n, int H, int W, int cin, int cout, int stride, const float* dw, const float* dbias,
-                       float dslope, const float* pw, const float* pbias, float pslope, hipStream_t s);
+                       float dslope, const float* pw, const float* pbias, float pslope, bool split, hipStream_t s);
 
 // y[n][h][w][c] += x[n][floor(h * Hs/H)][floor(w * Ws/W)][c]: F.interpolate(mode="nearest") + add
 // (retina_face_utils/components.py:88-94), fp32 NHWC
-hipError_t launch_upsample_add(const float* x, int Hs, int Ws, float* y, int H, int W, int C, int n, hipStream_t s);
+hipError_t launch_upsample_add(const float* x, int Hs, int Ws, float* y, int H, int W, int C, int n, bool split, hipStream_t s);
 
 // NHWC slice (dtype) -> NCHW fp32 (for taps / debugging)
 hipError_t launch_nhwc_to_nchw_f32(const void* x, int ldx, int dtype, float* y, int n, int HW, int C, hipStream_t s);

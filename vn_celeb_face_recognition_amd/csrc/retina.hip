@@ -20,6 +20,7 @@
 
 #include "engine.h"
 #include "nms_device.h"
+#include "split_f16.h"
 
 namespace vnf {
 
@@ -28,11 +29,14 @@ constexpr int RKEEP = 768;    // >= keep_top_k (750)
 
 struct RetinaGeom {
   int H, W, n_anchor;
+  int split;                      // the head maps hold split-f16 pairs (F16X2 plan) instead of fp32
   int fh[3], fw[3], off[3];       // feature map sizes, first anchor index of each level
   const float* head[3];           // (B, fh, fw, 32) fp32: [cls 4 | bbox 8 | landmark 20]
 };
 
 struct RCand { float score; int anchor; };
+
+__device__ __forceinline__ float hval(const RetinaGeom& g, const float* p) { return g.split ? (float)__builtin_bit_cast(sf16, *p) : *p; }
 
 __device__ __forceinline__ void anchor_loc(const RetinaGeom& g, int a, int& l, int& cell, int& k) {
   l = a >= g.off[2] ? 2 : (a >= g.off[1] ? 1 : 0);
@@ -55,17 +59,20 @@ __device__ __forceinline__ float4 decode_box(const RetinaGeom& g, int img, int a
   anchor_loc(g, a, l, cell, k);
   const float4 p = prior_of(g, l, cell, k);
   const float* h = g.head[l] + ((size_t)img * g.fh[l] * g.fw[l] + cell) * 32 + 4 + 4 * k;
-  const float bx = p.x + (h[0] * 0.1f) * p.z, by = p.y + (h[1] * 0.1f) * p.w;
-  const float bw = p.z * expf(h[2] * 0.2f), bh = p.w * expf(h[3] * 0.2f);
+  const float bx = p.x + (hval(g, h) * 0.1f) * p.z, by = p.y + (hval(g, h + 1) * 0.1f) * p.w;
+  const float bw = p.z * expf(hval(g, h + 2) * 0.2f), bh = p.w * expf(hval(g, h + 3) * 0.2f);
   const float x1 = bx - bw / 2.f, y1 = by - bh / 2.f;
   const float x2 = bw + x1, y2 = bh + y1;
   return float4{x1 * (float)g.W, y1 * (float)g.H, x2 * (float)g.W, y2 * (float)g.H};
 }
 
-__global__ void retina_prep_kernel(const uint8_t* __restrict__ frames, float* __restrict__ x, size_t npix) {
+__global__ void retina_prep_kernel(const uint8_t* __restrict__ frames, float* __restrict__ x, size_t npix, int split) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
     const uint8_t* p = frames + i * 3;
-    *reinterpret_cast<float4*>(x + i * 4) = float4{(float)p[0] - 104.f, (float)p[1] - 117.f, (float)p[2] - 123.f, 0.f};
+    float4 v = float4{(float)p[0] - 104.f, (float)p[1] - 117.f, (float)p[2] - 123.f, 0.f};
+    if (split)   // small integers: exact in the hi half
+      v = float4{__builtin_bit_cast(float, sf16(v.x)), __builtin_bit_cast(float, sf16(v.y)), __builtin_bit_cast(float, sf16(v.z)), 0.f};
+    *reinterpret_cast<float4*>(x + i * 4) = v;
   }
 }
 
@@ -76,8 +83,9 @@ __global__ void retina_score_kernel(RetinaGeom g, int B, float conf_thres, RCand
   int l, cell, k;
   anchor_loc(g, a, l, cell, k);
   const float* h = g.head[l] + ((size_t)img * g.fh[l] * g.fw[l] + cell) * 32 + 2 * k;
-  const float m = fmaxf(h[0], h[1]);
-  const float e0 = expf(h[0] - m), e1 = expf(h[1] - m);
+  const float l0 = hval(g, h), l1 = hval(g, h + 1);
+  const float m = fmaxf(l0, l1);
+  const float e0 = expf(l0 - m), e1 = expf(l1 - m);
   const float score = e1 / (e0 + e1);
   if (score > conf_thres) {
     const int slot = atomicAdd(&cnt[img], 1);
@@ -144,8 +152,8 @@ __global__ void __launch_bounds__(256) retina_select_kernel(RetinaGeom g, const 
       o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; o[4] = score;
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
-        o[5 + 2 * j] = (p.x + (h[2 * j] * 0.1f) * p.z) * (float)g.W;
-        o[6 + 2 * j] = (p.y + (h[2 * j + 1] * 0.1f) * p.w) * (float)g.H;
+        o[5 + 2 * j] = (p.x + (hval(g, h + 2 * j) * 0.1f) * p.z) * (float)g.W;
+        o[6 + 2 * j] = (p.y + (hval(g, h + 2 * j + 1) * 0.1f) * p.w) * (float)g.H;
       }
     }
   }
@@ -201,7 +209,11 @@ extern "C" int vnf_retina_create(const vnf_tensor_desc* weights, int n_weights, 
     WeightMap wm(weights, n_weights);
     r->enc = new Encoder();
     Encoder& e = *r->enc;
-    e.kind = 1; e.arch = -5; e.dtype = F32; e.max_batch = cfg->max_batch; e.max_streams = 1;
+    if (cfg->compute_dtype != VNF_F32 && cfg->compute_dtype != VNF_F16X2) {
+      delete r;
+      return fail(VNF_E_INVALID, "vnf_retina_create: compute_dtype must be VNF_F32 or VNF_F16X2");
+    }
+    e.kind = 1; e.arch = -5; e.dtype = cfg->compute_dtype == VNF_F16X2 ? F16X2 : F32; e.max_batch = cfg->max_batch; e.max_streams = 1;
     int rc = build_retina_mnet(e, wm, cfg->height, cfg->width, r->head_bufs);
     if (rc == VNF_OK) rc = e.finalize();
     if (rc != VNF_OK) { delete r; return rc; }
@@ -215,6 +227,7 @@ extern "C" int vnf_retina_create(const vnf_tensor_desc* weights, int n_weights, 
       g.head[l] = (const float*)hb.ptr;
     }
     g.n_anchor = acc;
+    g.split = e.dtype == F16X2 ? 1 : 0;
     const size_t B = cfg->max_batch;
     r->cand = (RCand*)r->dalloc(B * RCAP * sizeof(RCand));
     r->cnt = (int*)r->dalloc((2 * B + 8) * 4);
@@ -252,7 +265,7 @@ extern "C" int vnf_retina_detect(vnf_handle h, const uint8_t* frames, int b, int
     if (!stem_in_plan) {
       const size_t npix = (size_t)b * height * width;
       hipLaunchKernelGGL(retina_prep_kernel, dim3((unsigned)std::min<size_t>((npix + 255) / 256, 16384)), dim3(256), 0, s, frames,
-                         (float*)e.bufs[0].ptr, npix);
+                         (float*)e.bufs[0].ptr, npix, e.dtype == F16X2 ? 1 : 0);
       VNF_HIP(hipGetLastError());
     }
     static const bool layers = getenv("VNF_RETINA_LAYERS") != nullptr;   // diagnostic: per-layer table on stderr
@@ -321,5 +334,11 @@ extern "C" int vnf_retina_debug_heads(vnf_handle h, int level, int b, float* hos
   if (!host_out || total > capacity || b > r->cfg.max_batch) return fail(VNF_E_CAPACITY, "vnf_retina_debug_heads: capacity");
   VNF_HIP(hipDeviceSynchronize());
   VNF_HIP(hipMemcpy(host_out, bf.ptr, (size_t)total * 4, hipMemcpyDeviceToHost));
+  if (r->enc->dtype == F16X2)
+    for (int64_t i = 0; i < total; ++i) {
+      sf16 v;
+      memcpy(&v, host_out + i, 4);
+      host_out[i] = (float)v;
+    }
   return VNF_OK;
 }

@@ -26,7 +26,7 @@ class RetinaFace:
 
     def __init__(self, backbone_cfg="cfg_mnet", phase="test", backbone_path=None, device="cuda:0", conf_thres=0.02,
                  topk_bf_nms=5000, keep_top_k=750, nms_thres=0.4, vis_thres=0.6, checkpoint_path=None, state_dict=None,
-                 seed=0, max_batch=1):
+                 seed=0, max_batch=1, compute_dtype="f32"):
         if backbone_cfg != "cfg_mnet":
             raise NotImplementedError("RetinaFace: only backbone_cfg='cfg_mnet' (mobilenet0.25) is built for MI355X; %r "
                                       "needs the torchvision ResNet-50 download (retina_face.py:84-86)" % (backbone_cfg,))
@@ -40,6 +40,9 @@ class RetinaFace:
         self.nms_thres = float(nms_thres)
         self.vis_thres = float(vis_thres)
         self._max_batch = int(max_batch)
+        if compute_dtype not in ("f32", "f16x2"):
+            raise ValueError("RetinaFace compute_dtype: 'f32' (exact, default) or 'f16x2' (split-f16, ~15 %% faster), got %r" % (compute_dtype,))
+        self.compute_dtype = compute_dtype
         self._handle = None
         self._handle_key = None
         self._frames = None
@@ -93,6 +96,7 @@ class RetinaFace:
             cfg.height, cfg.width, cfg.max_batch = h, w, self._max_batch
             cfg.conf_thres, cfg.topk_bf_nms, cfg.nms_thres = self.conf_thres, self.topk_bf_nms, self.nms_thres
             cfg.keep_top_k, cfg.vis_thres = self.keep_top_k, self.vis_thres
+            cfg.compute_dtype = 5 if self.compute_dtype == "f16x2" else 0     # VNF_F16X2 / VNF_F32
             descs, n, keep = _lib.make_descs(self._sd)
             h_ = ctypes.c_void_p()
             _lib.check(lib.vnf_retina_create(descs, n, ctypes.byref(cfg), ctypes.byref(h_)))
