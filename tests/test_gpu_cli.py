@@ -268,3 +268,19 @@ def test_demo_video_1080p_npy_stream(tmp_path):
             total += 1
             found += any(inside(t, b) for b in boxes)
     assert total == 48 and found >= 40, (found, total)
+
+
+def test_demo_image_cli_with_the_retinaface_plugin(tmp_path):
+    """-det RetinaFace -dargs cfg/detection/retina_face.json (the detector the reference's own scripts select,
+    scripts/celeb_stat_*.sh): the CLI resolves it by name like the reference (demo_image.py:361-366)."""
+    ck, l2n = _classifier_files(tmp_path)
+    a = load_image("hoai_linh_4_recog.jpg")
+    from PIL import Image
+    src = str(tmp_path / "in.png")
+    Image.fromarray(a).save(src)
+    out_png = str(tmp_path / "out.png")
+    so = _run([os.path.join(REPO, "demo_image.py"), "-i", src, "-o", out_png, "-m", ck, "-l2n", l2n, "-enc", "InceptionResnetV1",
+               "-eargs", os.path.join(REPO, "cfg/embedding/inception_resnet_v1.json"), "-det", "RetinaFace",
+               "-dargs", os.path.join(REPO, "cfg/detection/retina_face.json"), "-tg_fs", "160", "--inference_method", "par_fd_vs_aln"],
+              str(tmp_path))
+    assert "Face recognized image saved at" in so and os.path.exists(out_png)
