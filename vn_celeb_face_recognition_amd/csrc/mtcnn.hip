@@ -113,7 +113,9 @@ __global__ void __launch_bounds__(256) pyramid_rows_kernel(const uint8_t* __rest
                                                             LevelTable t, float* __restrict__ lvl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned* colsum = reinterpret_cast<unsigned*>(smem);  // W*3 entries
-  int li = 0, r = blockIdx.x;
+  // workgroups are dispatched in blockIdx order: the rows of the SMALL levels (tall bins: tens of input rows each, the
+  // longest workgroups) go first, so they do not form the tail of the launch
+  int li = 0, r = (int)gridDim.x - 1 - (int)blockIdx.x;
   while (li + 1 < t.n && r >= t.l[li].Hs) { r -= t.l[li].Hs; ++li; }
   const LevelDesc L = t.l[li];
   const int img = blockIdx.y, i = r;
@@ -127,17 +129,42 @@ __global__ void __launch_bounds__(256) pyramid_rows_kernel(const uint8_t* __rest
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[q][j] = 0u;
     const int ca = c0 + threadIdx.x, cb = ca + 256;
-    for (int yy = h0; yy < h1; ++yy) {
-      const uint4* row = reinterpret_cast<const uint4*>(base + (size_t)yy * rowb);
-      uint4 va = ca < nchunk ? row[ca] : uint4{0u, 0u, 0u, 0u};
-      uint4 vb = cb < nchunk ? row[cb] : uint4{0u, 0u, 0u, 0u};
-      const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+    const int cac = min(ca, nchunk - 1), cbc = min(cb, nchunk - 1);   // clamped: unconditional loads, results dropped below
+    // packed accumulation: bytes 0,2 and 1,3 of every dword add up in two 16-bit lanes of one register (5 VALU ops per
+    // dword instead of 11); 256 rows of 255 fit in 16 bits, then the packed sums are flushed into the 32-bit ones
+    for (int y0 = h0; y0 < h1; y0 += 256) {
+      const int y1 = min(h1, y0 + 256);
+      unsigned pe[2][4], po[2][4];
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+      for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc[0][d * 4 + e] += (wa[d] >> (8 * e)) & 0xFFu;
-          acc[1][d * 4 + e] += (wb[d] >> (8 * e)) & 0xFFu;
+        for (int d = 0; d < 4; ++d) { pe[q][d] = 0u; po[q][d] = 0u; }
+      for (int yy = y0; yy < y1; yy += 2) {
+        // two rows per round, four 16-byte loads in flight; the second row is clamped and masked at an odd tail
+        // (four rows per round was slower: the bins of the first level are only 4-5 rows tall)
+        const int yb = min(yy + 1, y1 - 1);
+        const unsigned mb = (yy + 1 < y1) ? 0x00FF00FFu : 0u;
+        const uint4* r0 = reinterpret_cast<const uint4*>(base + (size_t)yy * rowb);
+        const uint4* r1 = reinterpret_cast<const uint4*>(base + (size_t)yb * rowb);
+        const uint4 v00 = r0[cac], v01 = r0[cbc], v10 = r1[cac], v11 = r1[cbc];
+        const unsigned w0[2][4] = {{v00.x, v00.y, v00.z, v00.w}, {v01.x, v01.y, v01.z, v01.w}};
+        const unsigned w1[2][4] = {{v10.x, v10.y, v10.z, v10.w}, {v11.x, v11.y, v11.z, v11.w}};
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            pe[q][d] += (w0[q][d] & 0x00FF00FFu) + (w1[q][d] & mb);
+            po[q][d] += ((w0[q][d] >> 8) & 0x00FF00FFu) + ((w1[q][d] >> 8) & mb);
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          acc[q][d * 4 + 0] += pe[q][d] & 0xFFFFu;
+          acc[q][d * 4 + 1] += po[q][d] & 0xFFFFu;
+          acc[q][d * 4 + 2] += pe[q][d] >> 16;
+          acc[q][d * 4 + 3] += po[q][d] >> 16;
         }
     }
     if (ca < nchunk) {
@@ -749,8 +776,9 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
   // per-byte column sums of input rows [h0,h1) of one 16-byte chunk column: four independent loads in flight per
   // step (clamped row + byte mask instead of a branch, so the loads are not serialised behind their predicates)
   auto colsum = [&](int c, int h0, int h1, unsigned (&acc)[16]) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0u;
+    // bytes 0,2 / 1,3 of each dword accumulate in the two 16-bit halves of one register (a bin has at most 257 rows
+    // here: deeper ones took the per-pixel path above), unpacked once at the end
+    unsigned pe[4] = {0u, 0u, 0u, 0u}, po[4] = {0u, 0u, 0u, 0u};
     const uint8_t* p0 = fbase + (size_t)y0 * rowb + ((size_t)(c_lo + c) << 4);
     for (int yy = h0; yy < h1; yy += 4) {
       uint4 v[4];
@@ -758,13 +786,21 @@ __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __
       for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const uint4*>(p0 + (size_t)min(yy + j, h1 - 1) * rowb);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const unsigned msk = (yy + j < h1) ? 0xFFu : 0u;
+        const unsigned msk = (yy + j < h1) ? 0x00FF00FFu : 0u;
         const unsigned wv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[d * 4 + e] += (wv[d] >> (8 * e)) & msk;
+        for (int d = 0; d < 4; ++d) {
+          pe[d] += wv[d] & msk;
+          po[d] += (wv[d] >> 8) & msk;
+        }
       }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      acc[d * 4 + 0] = pe[d] & 0xFFFFu;
+      acc[d * 4 + 1] = po[d] & 0xFFFFu;
+      acc[d * 4 + 2] = pe[d] >> 16;
+      acc[d * 4 + 3] = po[d] >> 16;
     }
   };
   if (nch <= 32) {
