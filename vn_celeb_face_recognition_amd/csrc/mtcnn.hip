@@ -1685,6 +1685,8 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
       const int need_img = CAP_IMG * 8 + KEEP * 20 + 256 * 20, need_scale = CAP_SCALE_MAX * 8 + KEEP * 20 + 256 * 20;   // per function, not per handle: the larger table
       const int need_post = KEEP * 44 + 256 * 20, need_r = (13552 + 3388 + 864) * 4, need_o = (16928 + 14112 + 6912 + 1152) * 4;
       (void)hipFuncSetAttribute((const void*)nms_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_img);
+      (void)hipFuncSetAttribute((const void*)net_front_kernel<24, 11, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+      (void)hipFuncSetAttribute((const void*)net_front_kernel<24, 11, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
       {
         int wmax = 0;
         for (int l = 0; l < m->cap_table.n; ++l) wmax = std::max(wmax, m->cap_table.l[l].Ws);
@@ -1823,9 +1825,11 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
         const bool split = enc->dtype == F16X2;
         const float* cin = (const float*)enc->bufs[0].ptr;
         float* pout = (float*)enc->bufs[1].ptr;
-        const size_t lr = (15 * 24 + 13 * 22 * 8) * 16, lo = (11 * 48 + 9 * 46 * 8) * 16;
-        if (S == 24 && split) hipLaunchKernelGGL((net_front_kernel<24, 6, 256, true>), dim3(2, n), dim3(256), lr, s, cin, m->rfw, pout);
-        else if (S == 24) hipLaunchKernelGGL((net_front_kernel<24, 6, 256, false>), dim3(2, n), dim3(256), lr, s, cin, m->rfw, pout);
+        const size_t lr = (25 * 24 + 22 * 22 * 8) * 16, lo = (11 * 48 + 9 * 46 * 8) * 16;   // (IR * S + conv rows * C * 8) float4
+        // R-Net: the whole candidate in one workgroup of 8 waves (no band overlap to recompute; measured 0.065 ms against
+        // 0.074 for two bands x 4 waves); O-Net: bands of 4 pooled rows x 8 waves (larger bands / 16 waves were slower)
+        if (S == 24 && split) hipLaunchKernelGGL((net_front_kernel<24, 11, 512, true>), dim3(1, n), dim3(512), lr, s, cin, m->rfw, pout);
+        else if (S == 24) hipLaunchKernelGGL((net_front_kernel<24, 11, 512, false>), dim3(1, n), dim3(512), lr, s, cin, m->rfw, pout);
         else if (split) hipLaunchKernelGGL((net_front_kernel<48, 4, 512, true>), dim3(6, n), dim3(512), lo, s, cin, m->ofw, pout);
         else hipLaunchKernelGGL((net_front_kernel<48, 4, 512, false>), dim3(6, n), dim3(512), lo, s, cin, m->ofw, pout);
         mark(S == 24 ? "rnet_front" : "onet_front", 0);
