@@ -1809,7 +1809,8 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   const bool crop_fast = (W * 3) % 16 == 0 && ((reinterpret_cast<uintptr_t>(frames)) & 15) == 0;
   auto crop = [&](const Row* rws, const int* cntp, int maxc, int S, float* dst, const int* offs, int c0, int cap) {
     if (crop_fast)
-      hipLaunchKernelGGL(crop_resize_rows_kernel, dim3(maxc, B, 4), dim3(256), 0, s, frames, H, W, rws, cntp, S, dst, m->status, offs, c0, cap);
+      // S / 8 row groups per candidate: 8 output rows per workgroup = 4 waves x 2 rows (measured best of 2..8 groups)
+      hipLaunchKernelGGL(crop_resize_rows_kernel, dim3(maxc, B, S / 8), dim3(256), 0, s, frames, H, W, rws, cntp, S, dst, m->status, offs, c0, cap);
     else
       hipLaunchKernelGGL(crop_resize_kernel, dim3(maxc, B), dim3(256), 0, s, frames, H, W, rws, cntp, S, dst, m->status, offs, c0, cap);
   };
