@@ -110,15 +110,17 @@ __global__ void pyramid_kernel(const uint8_t* __restrict__ frames, int H, int W,
 // output pixels then add their horizontal spans.  Integer sums, so the result is bit-identical to
 // the per-pixel kernel above and to the oracle.
 __global__ void __launch_bounds__(256) pyramid_rows_kernel(const uint8_t* __restrict__ frames, int H, int W,
-                                                            LevelTable t, float* __restrict__ lvl) {
+                                                            LevelTable t, float* __restrict__ lvl, const int* __restrict__ row_order) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned* colsum = reinterpret_cast<unsigned*>(smem);  // W*3 entries
-  // workgroups are dispatched in blockIdx order: the rows of the SMALL levels (tall bins: tens of input rows each, the
-  // longest workgroups) go first, so they do not form the tail of the launch
-  int li = 0, r = (int)gridDim.x - 1 - (int)blockIdx.x;
-  while (li + 1 < t.n && r >= t.l[li].Hs) { r -= t.l[li].Hs; ++li; }
+  // XCD-aware dispatch: blockIdx.x is the FRAME (workgroups go to the 8 XCDs round-robin in linear order, so with a
+  // multiple of 8 frames every frame stays on one XCD and its private L2), blockIdx.y walks the output rows of ALL levels
+  // in the order of the frame rows they read (row_order: sorted by the bin's first input row, tall bins first on ties):
+  // the nine levels' readers of a band of the frame run together and the band is fetched from beyond L2 once, not 9x
+  const int packed = row_order[blockIdx.y];
+  const int li = packed >> 16, r = packed & 0xFFFF;
   const LevelDesc L = t.l[li];
-  const int img = blockIdx.y, i = r;
+  const int img = blockIdx.x, i = r;
   const int h0 = (int)(((long long)i * H) / L.Hs), h1 = (int)((((long long)(i + 1)) * H + L.Hs - 1) / L.Hs);
   const int rowb = W * 3, nchunk = rowb >> 4;
   const uint8_t* base = frames + (size_t)img * H * rowb;
@@ -139,9 +141,10 @@ __global__ void __launch_bounds__(256) pyramid_rows_kernel(const uint8_t* __rest
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int d = 0; d < 4; ++d) { pe[q][d] = 0u; po[q][d] = 0u; }
+      // two rows per round, four 16-byte loads in flight; the second row is clamped and masked at an odd tail
+      // (slower: four rows per round -- the bins of the first level are only 4-5 rows tall; six-row rounds for the
+      // tall bins of the small levels, 0.154 ms -- more requests in flight only crowd the memory system)
       for (int yy = y0; yy < y1; yy += 2) {
-        // two rows per round, four 16-byte loads in flight; the second row is clamped and masked at an odd tail
-        // (four rows per round was slower: the bins of the first level are only 4-5 rows tall)
         const int yb = min(yy + 1, y1 - 1);
         const unsigned mb = (yy + 1 < y1) ? 0x00FF00FFu : 0u;
         const uint4* r0 = reinterpret_cast<const uint4*>(base + (size_t)yy * rowb);
@@ -1440,6 +1443,8 @@ struct Mtcnn : HandleBase {
   float *crops = nullptr, *rout = nullptr, *oout = nullptr, *fin = nullptr;
   float *prob_dbg = nullptr, *reg_dbg = nullptr;
   Encoder *renc = nullptr, *oenc = nullptr;  // R-Net / O-Net plans on the exact-f32 MFMA core (candidates = batch)
+  int* row_order = nullptr;                   // pyramid dispatch order (device), rebuilt when the frame size changes
+  int row_order_h = 0, row_order_w = 0, row_order_cap = 0;
   int cap_scale = CAP_SCALE;                  // stage-1 candidates per (level, frame): 4096 or 8192 (see vnf_mtcnn_create)
   int pnet1_lds = 0;                          // dynamic LDS granted to pnet_conv1_pool_mfma_kernel
   bool front = false;                         // conv1 + PReLU + pool1 of both nets by net_front_kernel (plans start at conv2)
@@ -1637,6 +1642,13 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
     // other aspect ratios up to the same bounds can need slightly more: 10 % head-room
     m->cap_px = (size_t)(m->cap_table.tot_px * 1.1) + 4096; m->cap_p1 = (size_t)(m->cap_table.tot_p1 * 1.1) + 4096;
     m->cap_c2 = (size_t)(m->cap_table.tot_c2 * 1.1) + 4096; m->cap_out = (size_t)(m->cap_table.tot_out * 1.1) + 4096;
+    {
+      int rows_cap = 0;
+      for (int l = 0; l < m->cap_table.n; ++l) rows_cap += m->cap_table.l[l].Hs;
+      m->row_order_cap = (int)(rows_cap * 1.1) + 64;
+      m->row_order = (int*)m->dalloc((size_t)m->row_order_cap * 4);
+      if (!m->row_order) { delete m; return VNF_E_HIP; }
+    }
     m->lvl = (float*)m->dalloc(m->cap_px * 3 * B * 4);
     m->p1 = (float*)m->dalloc(m->cap_p1 * 10 * B * 4);
     m->c2 = (float*)m->dalloc(m->cap_c2 * 16 * B * 4);
@@ -1755,7 +1767,22 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
     if (fast) {
       int rows = 0;
       for (int l = 0; l < t.n; ++l) rows += t.l[l].Hs;
-      hipLaunchKernelGGL(pyramid_rows_kernel, dim3(rows, B), dim3(256), (size_t)W * 12, s, frames, H, W, t, m->lvl);
+      if (rows > m->row_order_cap) return fail(VNF_E_CAPACITY, "mtcnn: pyramid exceeds handle capacity");
+      if (m->row_order_h != H || m->row_order_w != W) {
+        std::vector<std::pair<long long, int>> ord;     // (first input row, tall bins first) -> (level << 16 | row)
+        for (int l = 0; l < t.n; ++l)
+          for (int i = 0; i < t.l[l].Hs; ++i) {
+            const long long h0 = ((long long)i * H) / t.l[l].Hs;
+            ord.push_back({h0 * 64 + (63 - std::min(l, 63)), (l << 16) | i});
+          }
+        std::sort(ord.begin(), ord.end());
+        std::vector<int> packed(ord.size());
+        for (size_t k = 0; k < ord.size(); ++k) packed[k] = ord[k].second;
+        VNF_HIP(hipMemcpyAsync(m->row_order, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, s));
+        VNF_HIP(hipStreamSynchronize(s));              // the host vector goes away; happens once per frame size
+        m->row_order_h = H; m->row_order_w = W;
+      }
+      hipLaunchKernelGGL(pyramid_rows_kernel, dim3(B, rows), dim3(256), (size_t)W * 12, s, frames, H, W, t, m->lvl, m->row_order);
     } else {
       hipLaunchKernelGGL(pyramid_kernel, dim3((t.tot_px + 255) / 256, B), dim3(256), 0, s, frames, H, W, t, m->lvl);
     }
