@@ -367,10 +367,10 @@ __global__ void __launch_bounds__(256) pnet_conv1_pool_mfma_kernel(const float* 
 // two accumulator chains interleave, the next pair's loads issued before the current pair's MFMAs.  No barrier at all.
 __global__ void __launch_bounds__(256) pnet_conv1_pool_direct_kernel(const float* __restrict__ lvl, LevelTable t, PNetW w,
                                                                       float* __restrict__ p1) {
-  int li = 0, py = blockIdx.x;
+  int li = 0, py = blockIdx.y;   // frame on x: one XCD (and its L2) per frame, see pyramid_rows_kernel
   while (li + 1 < t.n && py >= t.l[li].Hp) { py -= t.l[li].Hp; ++li; }
   const LevelDesc L = t.l[li];
-  const int img = blockIdx.y, tid = threadIdx.x;
+  const int img = blockIdx.x, tid = threadIdx.x;
   const int Hc = L.Hs - 2, Wc = L.Ws - 2;
   const int wave = tid >> 6, lane = tid & 63, lg = lane >> 4, lm = lane & 15, dy = lm >> 3, dx = lm & 7;
   float wa[9];
@@ -437,9 +437,9 @@ __global__ void __launch_bounds__(256) pnet_conv1_pool_direct_kernel(const float
 
 // mtcnn.py:42-43: conv2 10->16 (3x3) + PReLU
 __global__ void pnet_conv2_kernel(const float* __restrict__ p1, LevelTable t, PNetW w, float* __restrict__ c2) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = blockIdx.y * blockDim.x + threadIdx.x;
   if (idx >= t.tot_c2) return;
-  const int img = blockIdx.y;
+  const int img = blockIdx.x;
   const int li = find_level(t, idx, 2);
   const LevelDesc L = t.l[li];
   const int p = idx - L.off_c2, y = p / L.W2, x = p - y * L.W2;
@@ -1796,14 +1796,14 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
     const size_t lds = ((size_t)12 * (wmax + 64) + (size_t)10 * ((wmax - 1) / 2)) * 4;
     static const int p1_mode = getenv("VNF_PNET1") ? atoi(getenv("VNF_PNET1")) : 2;   // 0 VALU, 1 MFMA via LDS, 2 MFMA direct
     if (p1_mode == 2)
-      hipLaunchKernelGGL(pnet_conv1_pool_direct_kernel, dim3(rows, B), dim3(256), 0, s, m->lvl, t, m->pw, m->p1);
+      hipLaunchKernelGGL(pnet_conv1_pool_direct_kernel, dim3(B, rows), dim3(256), 0, s, m->lvl, t, m->pw, m->p1);
     else if (p1_mode == 1 && lds <= (size_t)m->pnet1_lds)
       hipLaunchKernelGGL(pnet_conv1_pool_mfma_kernel, dim3(rows, B), dim3(256), lds, s, m->lvl, t, m->pw, m->p1);
     else
       hipLaunchKernelGGL(pnet_conv1_pool_kernel, dim3((t.tot_p1 + 255) / 256, B), dim3(256), 0, s, m->lvl, t, m->pw, m->p1);
   }
   mark("pnet_conv1_pool", fB * ((double)t.tot_px * 12 + (double)t.tot_p1 * 40));
-  hipLaunchKernelGGL(pnet_conv2_kernel, dim3((t.tot_c2 + 255) / 256, B), dim3(256), 0, s, m->p1, t, m->pw, m->c2);
+  hipLaunchKernelGGL(pnet_conv2_kernel, dim3(B, (t.tot_c2 + 255) / 256), dim3(256), 0, s, m->p1, t, m->pw, m->c2);
   mark("pnet_conv2", fB * ((double)t.tot_p1 * 40 + (double)t.tot_c2 * 64));
   hipLaunchKernelGGL(pnet_conv3_heads_kernel, dim3((t.tot_out + 255) / 256, B), dim3(256), 0, s, m->c2, t, m->pw,
                      cfg.thresholds[0], B, m->cap_scale, m->cand, m->cand_cnt, m->status, m->prob_dbg, m->reg_dbg);
