@@ -288,3 +288,27 @@ def test_fused_stem_2a_2b_maxpool_is_bitwise_the_three_launch_plan(monkeypatch, 
     assert len(bad) == 0, (len(bad), bad[:8], pf[tuple(bad[0])], want[tuple(bad[0])])
     assert np.array_equal(fused.tap("conv2d_4b", k), plain.tap("conv2d_4b", k))
     assert torch.equal(yf, yp)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_conv2d_3b_inside_the_stem_kernel_is_bitwise_the_plan(dt, monkeypatch):
+    """VNF_FUSE bit 3: conv2d_3b (1x1, 64 -> 80, inception_resnet_v1.py:286) applied to every pooled row inside
+    stem_mid_kernel (the pooled tensor never reaches memory) -- same MFMA k order, bias after the sum, 16-bit rounding
+    of the pooled row and of the output as the plan's convolution: bit-identical conv2d_3b output and embeddings."""
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    n = 19
+    x = torch.randn((n, 3, 160, 160), generator=torch.Generator().manual_seed(7)).cuda()
+    monkeypatch.setenv("VNF_FUSE", "12")     # stem kernel + conv2d_3b inside it
+    fused = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=n).eval()
+    yf = fused(x).cpu().numpy()
+    tf_ = fused.tap("conv2d_3b", n)
+    monkeypatch.setenv("VNF_FUSE", "4")      # stem kernel, conv2d_3b as a plan convolution
+    mid = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=n).eval()
+    ym = mid(x).cpu().numpy()
+    tm = mid.tap("conv2d_3b", n)
+    monkeypatch.setenv("VNF_FUSE", "0")
+    plain = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=n).eval()
+    yp = plain(x).cpu().numpy()
+    assert tf_.shape == tm.shape == (n, 80, 38, 38)
+    assert np.array_equal(tf_, tm)
+    assert np.array_equal(yf, ym) and np.array_equal(yf, yp)

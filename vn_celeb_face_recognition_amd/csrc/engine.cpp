@@ -173,7 +173,7 @@ int Encoder::autotune() {
     for (int oi = g.first; oi < g.last; ++oi) {
       if (ops[oi].kind != Op::CONV) continue;
       bool in_fused = false;
-      for (const FusedStack& f : fused) in_fused |= f.active && oi >= f.first && oi < f.last;
+      for (const FusedStack& f : fused) in_fused |= f.active && oi >= f.first && oi < (f.ext ? f.ext_last : f.last);
       if (in_fused) continue;  // replaced by a persistent kernel: nothing to tune
       ConvLayer& L = convs[ops[oi].a];
       float best = 1e30f;
@@ -268,7 +268,8 @@ int Encoder::finalize() {
 // Fused stacks: the per-wave weight streams are gathered on the device from the packed per-convolution weights the
 // plan already uploaded (same folding, same k order), biases are concatenated per block.
 int Encoder::prepare_fused() {
-  const int enabled = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 7;  // bit 0: Block17 stack, bit 1: Block35, bit 2: stem 2a+2b+pool; read at create time
+  // bit 0: Block17 stack, bit 1: Block35, bit 2: stem 2a+2b+pool, bit 3: conv2d_3b inside the stem kernel; read at create time
+  const int enabled = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 15;
   for (FusedStack& f : fused) {
     f.active = false;
     if (!enabled || (dtype != BF16 && dtype != F16) || f.nblocks < 1 || f.nblocks > T17_MAX_BLOCKS) continue;
@@ -290,6 +291,15 @@ int Encoder::prepare_fused() {
       VNF_HIP(hipDeviceSynchronize());
       f.macs_alg = c2a.macs_alg + c2b.macs_alg;
       f.active = true;
+      f.ext = false;
+      if ((enabled & 8) && f.ext_conv >= 0) {
+        const ConvLayer& c3b = convs[f.ext_conv];
+        if (c3b.cout == 80 && c3b.K == 64 && c3b.KH == 1 && c3b.ncls == 1 && c3b.nseg == 1 && c3b.res_buf < 0 && c3b.act == ACT_RELU &&
+            bufs[f.ext_out_buf].C == 80) {
+          f.ext = true;
+          f.macs_alg += c3b.macs_alg;
+        }
+      }
       continue;
     }
     if (f.kind == 35) {
@@ -590,9 +600,10 @@ int build_irv1(Encoder& e, WeightMap& wm) {
     TRY(simple("conv2d_2b", b_2a, 0, 32, 32, 64, 3, 3, 1, 1, 1, b_2b, 0));
     add_maxpool(e, b_2b, b_3a, 0);
     f.last = (int)e.ops.size();
+    TRY(simple("conv2d_3b", b_3a, 0, 64, 64, 80, 1, 1, 1, 0, 0, b_3b, 0));
+    f.ext_last = (int)e.ops.size(); f.ext_conv = (int)e.convs.size() - 1; f.ext_out_buf = b_3b;
     e.fused.push_back(f);
   }
-  TRY(simple("conv2d_3b", b_3a, 0, 64, 64, 80, 1, 1, 1, 0, 0, b_3b, 0));
   TRY(simple("conv2d_4a", b_3b, 0, 80, 80, 192, 3, 3, 1, 0, 0, b_4a, 0));
   TRY(simple("conv2d_4b", b_4a, 0, 192, 192, 256, 3, 3, 2, 0, 0, x35[0], 0));
   const int stem_end = (int)e.ops.size();
@@ -700,7 +711,7 @@ int build_irv1(Encoder& e, WeightMap& wm) {
   // unfused, the stem runs in sub-batches of 128 images so its big producer -> consumer tensors stay inside the
   // Infinity Cache; with conv2d_2a/2b/maxpool fused (one workgroup per image, no big intermediate) a sub-batch would
   // only leave half the CUs without a workgroup
-  const int fuse_mask = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 7;
+  const int fuse_mask = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 15;
   int chunk = ((fuse_mask & 4) && (e.dtype == BF16 || e.dtype == F16)) ? 256 : 128;
   if (const char* c = getenv("VNF_STEM_CHUNK")) chunk = atoi(c) > 0 ? atoi(c) : chunk;
   e.groups.push_back({0, stem_end, chunk});
@@ -1277,9 +1288,17 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
           sa.y = ob.ptr + (size_t)n0 * ob.elems_per_image() * es;
           sa.ldx = ib.C; sa.ldy = ob.C; sa.n = nn;
           sa.wfrag = fs->wstream; sa.bias = fs->bias;
+          sa.w3b = nullptr; sa.b3b = nullptr; sa.k3b_pad = 0;
+          if (fs->ext) {
+            const ConvLayer& c3b = convs[fs->ext_conv];
+            const Buf& eb = bufs[fs->ext_out_buf];
+            sa.y = eb.ptr + (size_t)n0 * eb.elems_per_image() * es;
+            sa.ldy = eb.C;
+            sa.w3b = c3b.w; sa.b3b = c3b.bias; sa.k3b_pad = c3b.Kpad;
+          }
           hipError_t err = launch_stem_mid(sa, dtype, s);
           if (err != hipSuccess) return fail(VNF_E_HIP, std::string("fused stem: ") + hipGetErrorString(err));
-          oi = fs->last - 1;
+          oi = (fs->ext ? fs->ext_last : fs->last) - 1;
           continue;
         }
         if (fs && fs->kind == 35) {
@@ -1423,12 +1442,12 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
       total += ms[oi];
       const FusedStack* fs = nullptr;
       for (const FusedStack& f : fused)
-        if (f.active && (int)oi >= f.first && (int)oi < f.last) fs = &f;
+        if (f.active && (int)oi >= f.first && (int)oi < (f.ext ? f.ext_last : f.last)) fs = &f;
       if (fs) {
         if ((int)oi != fs->first) continue;
         const double gf = 2.0 * fs->macs_alg * n / 1e9;
         snprintf(line, sizeof line, "%-28s %-60s %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n",
-                 fs->kind == 35 ? "repeat_1 (fused blocks)" : fs->kind == 2 ? "conv2d_2a+2b+maxpool_3a" : "repeat_2 (persistent trunk)",
+                 fs->kind == 35 ? "repeat_1 (fused blocks)" : fs->kind == 2 ? (fs->ext ? "conv2d_2a+2b+maxpool_3a+3b" : "conv2d_2a+2b+maxpool_3a") : "repeat_2 (persistent trunk)",
                  fs->kind == 35 ? "5 x Block35, one launch per block, one workgroup per image"
                  : fs->kind == 2 ? "rolling rows, one launch, one workgroup per image"
                                  : "10 x Block17 in one launch, one workgroup per image",

@@ -102,6 +102,9 @@ struct FusedStack {
   float* bias = nullptr;
   bool active = false;
   double macs_alg = 0;         // per image
+  // kind 2 only: conv2d_3b (the op after the pool) folded into the stem kernel: ops [first, ext_last) become one launch
+  int ext_last = 0, ext_conv = -1, ext_out_buf = -1;
+  bool ext = false;
 };  // ops [first,last) run per `chunk` images (L3 residency)
 
 struct Tap { int buf, coff, C; };

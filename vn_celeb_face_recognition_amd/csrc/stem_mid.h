@@ -14,6 +14,11 @@ struct StemMidArgs {
   int ldx, ldy, n;
   const void* wfrag;   // stem_mid_repack output
   const float* bias;   // [SM_BIAS]
+  // optional: conv2d_3b (1x1, 64 -> 80, folded BN, ReLU) applied to every pooled row before it leaves the kernel; y is
+  // then the (n, 38, 38, ldy) conv2d_3b output and the pooled tensor never reaches memory
+  const void* w3b;     // packed engine weights [>= 80 rows][k3b_pad], 16-bit; nullptr: no fusion
+  const float* b3b;    // [80]
+  int k3b_pad;
 };
 
 struct StemMidPack {    // packed engine weights [rows][kpad], k = (kh, kw, c): conv2d_2a (32 x 288), conv2d_2b (64 x 288)

@@ -40,7 +40,9 @@ constexpr int IN_RING = 12, A2_RING = 4, B2_RING = 6;
 constexpr int AHEAD = 8;               // rows the input DMA runs ahead of conv2d_2a (HBM latency is several steps)
 constexpr int OFF_IN = 0, OFF_A2 = OFF_IN + IN_RING * IN_ROW, OFF_B2 = OFF_A2 + A2_RING * A2_ROW;
 constexpr int OFF_ZROW = OFF_B2 + B2_RING * B2_ROW;   // zero row (2b's vertical padding)
-constexpr int SM_LDS = OFF_ZROW + A2_ROW;
+constexpr int P_ROW = 38 * 128;                       // pooled row (conv2d_3b fusion): 38 px x 64 ch, layout of a 2b row
+constexpr int OFF_P = OFF_ZROW + A2_ROW;              // two pooled rows (written at odd steps, consumed one step later)
+constexpr int SM_LDS = OFF_P + 2 * P_ROW;
 
 template <typename T> struct MmaS;
 template <> struct MmaS<__bf16> {
@@ -120,6 +122,21 @@ __global__ __launch_bounds__(512, 2) void stem_mid_kernel(const StemMidArgs a) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) wf[t] = reinterpret_cast<const uint4*>(a.wfrag)[(size_t)(wtile * 9 + t) * 64 + lane];
   const f32x4_t bias = *reinterpret_cast<const f32x4_t*>(a.bias + (is2b ? 32 + 16 * wave : 16 * (wave & 1)) + 4 * fgrp);
+  // conv2d_3b on the pooled rows (waves 4..7): wave 4+j owns output-channel tile j for the three pixel tiles, and the
+  // fifth tile (channels 64..79) is shared: wave 4+i takes its pixel tile i.  Two A-fragments (K = 64) per channel tile.
+  const bool f3b = a.w3b != nullptr;
+  uint4 w3[2][2] = {{uint4{0u, 0u, 0u, 0u}, uint4{0u, 0u, 0u, 0u}}, {uint4{0u, 0u, 0u, 0u}, uint4{0u, 0u, 0u, 0u}}};
+  f32x4_t b3[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+  if (f3b && !is2b) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ct = u == 0 ? wave - 4 : 4;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        w3[u][ks] = *reinterpret_cast<const uint4*>((const char*)a.w3b + ((size_t)(16 * ct + frow) * a.k3b_pad + 32 * ks + 8 * fgrp) * 2);
+      b3[u] = *reinterpret_cast<const f32x4_t*>(a.b3b + 16 * ct + 4 * fgrp);
+    }
+  }
   // pixel tiles of this wave: 2b waves 0..4; 2a waves 4,5: 0..2, waves 6,7: 3..4
   const int pt0 = is2b ? 0 : (wave < 6 ? 0 : 3), npt = is2b ? 5 : (wave < 6 ? 3 : 2);
 
@@ -175,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void stem_mid_kernel(const StemMidArgs a) {
   using N3 = std::integral_constant<int, 3>;
   using N5 = std::integral_constant<int, 5>;
 
-  for (int s = 0; s < 80; ++s) {
+  for (int s = 0; s < (f3b ? 81 : 80); ++s) {
     if (is2b) {
       const int b = s - 2;   // 2b output row
       if (b >= 0 && b < W2) {
@@ -234,7 +251,41 @@ __global__ __launch_bounds__(512, 2) void stem_mid_kernel(const StemMidArgs a) {
 #pragma unroll
               for (int dx = 0; dx < 3; ++dx) m = max8(m, *reinterpret_cast<const uint4*>(rp + pl[it][dx]));
             }
-            *reinterpret_cast<uint4*>(yg + ((size_t)(p * WP + ox) * a.ldy + ch * 8) * 2) = m;
+            if (f3b) *reinterpret_cast<uint4*>(smem + OFF_P + (p & 1) * P_ROW + ox * 128 + ((ch ^ (ox & 7)) << 4)) = m;
+            else *reinterpret_cast<uint4*>(yg + ((size_t)(p * WP + ox) * a.ldy + ch * 8) * 2) = m;
+          }
+        }
+      }
+      if (f3b && s >= 6 && ((s - 6) & 1) == 0) {
+        // conv2d_3b of pooled row p (in LDS since the previous step): same k order and rounding points as the plan's
+        // 1x1 convolution (two 32-deep MFMA steps, bias after the sum, ReLU, 16-bit store)
+        const int p = (s - 6) >> 1;
+        const char* pr = smem + OFF_P + (p & 1) * P_ROW;
+        auto bfrag = [&](int pt, int ks) {
+          const int px = min(16 * pt + frow, WP - 1);
+          return *reinterpret_cast<const uint4*>(pr + px * 128 + (((4 * ks + fgrp) ^ (px & 7)) << 4));
+        };
+        auto emit = [&](int ct, int pt, const f32x4_t& acc, const f32x4_t& bb) {
+          const int px = 16 * pt + frow;
+          if (px < WP) {
+            f32x4_t v = acc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bb[e], 0.f);
+            *reinterpret_cast<uint2*>(yg + ((size_t)(p * WP + px) * a.ldy + 16 * ct + 4 * fgrp) * 2) = pack4s<T>(v);
+          }
+        };
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt) {
+          const uint4 x0 = bfrag(pt, 0), x1 = bfrag(pt, 1);
+          f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+          acc = MmaS<T>::run(w3[0][0], x0, acc);
+          acc = MmaS<T>::run(w3[0][1], x1, acc);
+          emit(wave - 4, pt, acc, b3[0]);
+          if (pt == wave - 4) {       // wave-uniform: the shared fifth channel tile, this wave's pixel tile
+            f32x4_t acc4 = {0.f, 0.f, 0.f, 0.f};
+            acc4 = MmaS<T>::run(w3[1][0], x0, acc4);
+            acc4 = MmaS<T>::run(w3[1][1], x1, acc4);
+            emit(4, pt, acc4, b3[1]);
           }
         }
       }
