@@ -103,7 +103,7 @@ def make_detector(args, models, dev, nf, per):
     """--detector mtcnn (the reference's default, cfg/detection/mtcnn.json) | retina (RetinaFace mobilenet0.25 with the
     generator's synthetic weights: keep_top_k = the pasted faces per frame, so the stages after it see the same load)."""
     if args.detector == "retina":
-        return models.RetinaFace("cfg_mnet", device=dev, max_batch=nf, keep_top_k=per, vis_thres=0.0)   # exact-f32 plan (default)
+        return models.RetinaFace("cfg_mnet", device=dev, max_batch=nf, keep_top_k=per, vis_thres=0.0, synthetic=True)   # exact-f32 plan (default)
     return models.MTCNN(keep_all=True, min_face_size=50, device=dev, max_batch=nf, max_height=1080, max_width=1920)
 
 

@@ -312,3 +312,19 @@ def test_conv2d_3b_inside_the_stem_kernel_is_bitwise_the_plan(dt, monkeypatch):
     assert tf_.shape == tm.shape == (n, 80, 38, 38)
     assert np.array_equal(tf_, tm)
     assert np.array_equal(yf, ym) and np.array_equal(yf, yp)
+
+
+def test_taps_inside_an_active_fused_kernel_are_refused(monkeypatch):
+    """With the fused stem (bf16 / f16, default VNF_FUSE) conv2d_2a, conv2d_2b and maxpool_3a only ever exist in LDS:
+    vnf_encoder_tap must say so instead of serving a never-written buffer; taps the fused kernels DO produce work."""
+    from vn_celeb_face_recognition_amd import _lib
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    monkeypatch.delenv("VNF_FUSE", raising=False)
+    m = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype="bf16", max_batch=2).eval()
+    m(seeded_normal((2, 3, 160, 160), 5).cuda())
+    for name in ("conv2d_2a", "conv2d_2b", "maxpool_3a"):
+        with pytest.raises(_lib.VnfError, match="fused kernel"):
+            m.tap(name, 2)
+    for name, c in (("conv2d_1a", 32), ("conv2d_3b", 80), ("repeat_1", 256), ("repeat_2", 896)):
+        t = m.tap(name, 2)
+        assert t.shape[:2] == (2, c) and np.isfinite(t).all() and np.abs(t).max() > 0

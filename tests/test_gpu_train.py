@@ -88,3 +88,16 @@ def test_resume_continues_bit_for_bit(tmp_path):
     cp_f = torch.load(os.path.join(str(full.save_dir), "checkpoint-epoch6.pth"), weights_only=True)
     assert float(cp_b["optimizer"]["state"][0]["step"]) == float(cp_f["optimizer"]["state"][0]["step"]) == 2 * float(cp_a["optimizer"]["state"][0]["step"])
     assert cp_b["epoch"] == 6 and cp_b["monitor_best"] < cp_a["monitor_best"]
+
+
+def test_out_of_range_label_raises_like_nll_loss():
+    """F.nll_loss asserts on a target outside [0, num_classes) (trainer/classification_trainer.py:22); the device kernel
+    would otherwise index past the row."""
+    from vn_celeb_face_recognition_amd.trainer import TrainableMLP
+    m = TrainableMLP(512, 12, max_batch=8, device="cuda:0")
+    x = torch.randn((4, 512), generator=torch.Generator().manual_seed(1))
+    loss, hits = m.step(x, torch.tensor([0, 3, 11, 5]), train=False)
+    assert np.isfinite(loss) and 0 <= hits <= 4
+    for bad in ([0, 12, 1, 2], [0, -1, 1, 2]):
+        with pytest.raises(IndexError, match="out of bounds"):
+            m.step(x, torch.tensor(bad), train=False)

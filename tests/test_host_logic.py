@@ -189,7 +189,7 @@ class _StubPipe:
         pass
 
 
-def _stream_worker(rank, world, port, q, n_total, n_frames):
+def _stream_worker(rank, world, port, q, n_total, n_frames, cap=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     sys.path.insert(0, REPO)
@@ -202,7 +202,7 @@ def _stream_worker(rank, world, port, q, n_total, n_frames):
         frames[i, :, :, 0], frames[i, :, :, 1] = (i + 1) % 251, (i + 1) // 251
     src = FrameSource(frames, 25.0)
     pipe = _StubPipe()
-    rows, processed = run_stream(src, pipe, n_frames, rank, world, device="cpu")
+    rows, processed = run_stream(src, pipe, n_frames, rank, world, device="cpu", cap=cap)
     q.put((rank, processed, src.reads, pipe.submitted, "".join(rows[k] for k in sorted(rows)) if rank == 0 else ""))
     dist.barrier()
     dist.destroy_process_group()
@@ -237,6 +237,47 @@ def test_video_stream_control_flow_two_ranks_gloo():
     assert sub0 == [[1, 2, 3, 4], [9, 10, 11, 12], [17, 18, 19, 20]]
     assert sub1 == [[5, 6, 7, 8], [13, 14, 15, 16], [21, 22, 23]]
     assert text0 == want
+
+
+def _frames_for(n_total):
+    frames = np.zeros((n_total, 4, 6, 3), np.uint8)
+    for i in range(n_total):
+        frames[i, :, :, 0], frames[i, :, :, 1] = (i + 1) % 251, (i + 1) // 251
+    return frames
+
+
+@pytest.mark.parametrize("n_total,n_frames,cap", [(19, 4, None), (3, 4, None), (23, 4, 2), (40, 4, None)])
+def test_video_stream_uneven_rounds_two_ranks_gloo(n_total, n_frames, cap):
+    """Collective order when the ranks own different numbers of batches (5 batches: rank 0 has 3 rounds, rank 1 has 2;
+    1 batch: rank 1 has none), more rounds than the retire lag (10 batches), and a fixed block too small for a batch
+    (cap 2 < faces per batch: the follow-up gather): every rank must issue round 0..R-1's exchange in the same order.
+    Rows must equal the single-process run's."""
+    import torch.multiprocessing as mp
+    from vn_celeb_face_recognition_amd.video import FrameSource, run_stream
+    rows1, p1 = run_stream(FrameSource(_frames_for(n_total), 25.0), _StubPipe(), n_frames, 0, 1, device="cpu")
+    want = "".join(rows1[k] for k in sorted(rows1))
+    assert p1 == n_total and sorted(rows1) == list(range(1, n_total + 1))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + (os.getpid() % 2000) + n_total
+    procs = [ctx.Process(target=_stream_worker, args=(r, 2, port, q, n_total, n_frames, cap)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert res[0][1] + res[1][1] == n_total
+    assert res[0][4] == want
+
+
+def test_video_stream_iterator_source_single_process():
+    """a decoder-like source (plain iterator): the frame total is only known once it is exhausted"""
+    from vn_celeb_face_recognition_amd.video import FrameSource, run_stream
+    frames = _frames_for(11)
+    rows_a, _ = run_stream(FrameSource(frames, 25.0), _StubPipe(), 4, 0, 1, device="cpu")
+    src = FrameSource(iter(list(frames)), 25.0)
+    rows_b, pb = run_stream(src, _StubPipe(), 4, 0, 1, device="cpu")
+    assert pb == 11 and src.total == 11 and rows_a == rows_b
 
 
 def test_cli_helpers(tmp_path):

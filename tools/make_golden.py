@@ -479,6 +479,6 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_shim()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["irv1", "mlp", "ir100", "mtcnn", "umeyama", "celeb_stat"]
+    which = sys.argv[1:] or ["irv1", "mlp", "ir100", "mtcnn", "umeyama", "celeb_stat", "retina", "mlp_train"]
     for w in which:
         globals()["golden_" + w]()

@@ -90,6 +90,9 @@ int vnf_encoder_tap(vnf_handle h, const char* name, int n, float* host_out, int6
   if (!e || !name) return fail(VNF_E_INVALID, "not an encoder handle");
   auto it = e->taps.find(name);
   if (it == e->taps.end()) return fail(VNF_E_INVALID, std::string("no such tap: ") + name);
+  if (!e->buf_materialised(it->second.buf))
+    return fail(VNF_E_INVALID, std::string("tap '") + name + "' is computed inside a fused kernel and never reaches memory in this "
+                "compute dtype: create the encoder under VNF_FUSE=0 (or use a dtype without fused stacks) to read it");
   const Buf& b = e->bufs[it->second.buf];
   const int C = it->second.C;
   const int64_t total = (int64_t)n * C * b.H * b.W;

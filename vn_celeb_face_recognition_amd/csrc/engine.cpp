@@ -354,6 +354,33 @@ int Encoder::prepare_fused() {
   return VNF_OK;
 }
 
+// A tap's buffer exists in memory unless every op that writes it sits inside an active fused stack and the stack's own
+// kernel does not produce it (conv2d_2a / conv2d_2b / maxpool_3a with the fused stem: those tensors only ever live in LDS).
+bool Encoder::buf_materialised(int buf) const {
+  for (const FusedStack& f : fused) {
+    if (!f.active) continue;
+    const int end = f.ext ? f.ext_last : f.last;
+    bool written = false;
+    for (int oi = f.first; oi < end; ++oi) {
+      const Op& op = ops[oi];
+      if (op.kind == Op::CONV) {
+        const ConvLayer& L = convs[op.a];
+        for (int i = 0; i < L.nseg; ++i) written |= L.seg[i].buf == buf;
+      } else if (op.kind == Op::MAXPOOL || op.kind == Op::MAXPOOLC) {
+        written |= op.b == buf;
+      }
+    }
+    if (!written) continue;
+    bool produced = false;
+    if (f.kind == 2) produced = buf == (f.ext ? f.ext_out_buf : f.out_buf);
+    else if (f.kind == 35)
+      for (int b = 0; b < f.nblocks; ++b) produced |= convs[f.conv0 + 5 * b + 4].seg[0].buf == buf;
+    else produced = buf == f.out_buf;
+    if (!produced) return false;
+  }
+  return true;
+}
+
 struct Piece {  // output channels contributed by one reference conv / linear
   const float* w;  // [cout][cin][KH][KW]
   int cout, cout_pad;

@@ -122,6 +122,7 @@ struct Encoder : HandleBase {
   std::vector<FusedStack> fused;
   int prepare_fused();  // build the weight streams of the fused stacks (finalize)
   std::unordered_map<std::string, Tap> taps;
+  bool buf_materialised(int buf) const;  // false: only ops that an ACTIVE fused stack replaces would write it
   float* emb_raw = nullptr;  // (max_batch,512) fp32 before the final normalisation
   double macs_alg = 0, macs_exec = 0;
 

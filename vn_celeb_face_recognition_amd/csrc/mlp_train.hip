@@ -116,11 +116,15 @@ __global__ void softmax_nll_kernel(const float* __restrict__ z, int C, int Bn, c
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   const float ls = logf(s);
-  const int t = (int)target[row];
+  // a label outside [0, C) (torch's NLLLoss asserts on it; the host layer raises before the launch) never indexes the
+  // row: its loss term is NaN, so the step's loss shows it, and no out-of-range address is formed
+  const long long tl = (long long)target[row];
+  const bool tok = tl >= 0 && tl < (long long)C;
+  const int t = tok ? (int)tl : -1;
   if (dz)
     for (int c = lane; c < C; c += 64) dz[(size_t)row * C + c] = (expf((x[c] - m) - ls) - (c == t ? 1.f : 0.f)) * inv_b;
   if (lane == 0) {
-    loss_rows[row] = -((x[t] - m) - ls);
+    loss_rows[row] = tok ? -((x[t] - m) - ls) : __builtin_nanf("");
     hit_rows[row] = mi == t ? 1 : 0;
   }
 }
@@ -230,8 +234,9 @@ extern "C" int vnf_mlp_trainer_create(const vnf_tensor_desc* weights, int n_weig
       t->m[i] = (float*)t->dalloc(ne[i] * 4);
       t->v[i] = (float*)t->dalloc(ne[i] * 4);
       if (!t->p[i] || !t->g[i] || !t->m[i] || !t->v[i]) { delete t; return VNF_E_HIP; }
-      VNF_HIP(hipMemset(t->m[i], 0, ne[i] * 4));
-      VNF_HIP(hipMemset(t->v[i], 0, ne[i] * 4));
+      hipError_t me = hipMemset(t->m[i], 0, ne[i] * 4);
+      if (me == hipSuccess) me = hipMemset(t->v[i], 0, ne[i] * 4);
+      if (me != hipSuccess) { delete t; return fail(VNF_E_HIP, std::string("vnf_mlp_trainer_create: hipMemset: ") + hipGetErrorString(me)); }
     }
     float** bufs[] = {&t->h, &t->pre, &t->z, &t->dz, &t->dh, &t->dzT, &t->hT, &t->dhT, &t->xT, &t->w2T, &t->loss_rows};
     const size_t sz[] = {B * H, B * H, B * C, B * C, B * H, C * B, H * B, H * B, D * B, H * C, B};
@@ -241,7 +246,8 @@ extern "C" int vnf_mlp_trainer_create(const vnf_tensor_desc* weights, int n_weig
     }
     t->hit_rows = (int*)t->dalloc(B * 4);
     if (!t->hit_rows) { delete t; return VNF_E_HIP; }
-    VNF_HIP(hipDeviceSynchronize());
+    const hipError_t se = hipDeviceSynchronize();
+    if (se != hipSuccess) { delete t; return fail(VNF_E_HIP, std::string("vnf_mlp_trainer_create: ") + hipGetErrorString(se)); }
     *out = reinterpret_cast<vnf_handle>(static_cast<HandleBase*>(t));
     return VNF_OK;
   } catch (const std::exception& ex) {

@@ -311,8 +311,9 @@ class FacePipeline:
                 t.error = e
             t.done.set()
 
-    def submit(self, frames_dev, classify=True):
-        """Throughput mode: enqueue one frame batch and return a ticket without waiting for it.
+    def submit(self, frames_dev, classify=True, ready=None):
+        """Throughput mode: enqueue one frame batch and return a ticket without waiting for it.  `ready`: event after
+        which frames_dev is resident (upload.FrameUploader's copy stream); default: the caller's current stream.
 
         Detection runs on a detection stream (it synchronises with the host three times to size the candidate
         tables: detect_face.py's own stage boundaries); alignment + embedding (+ classification) run on the
@@ -341,7 +342,8 @@ class FacePipeline:
                                  for k in range(len(self.detectors))]
                 for th in self._threads:
                     th.start()
-        ready = torch.cuda.current_stream(dev).record_event()
+        if ready is None:
+            ready = torch.cuda.current_stream(dev).record_event()
         t = Ticket()
         if len(self.detectors) == 1:
             self._detect_embed(0, frames_dev, ready, t, classify)

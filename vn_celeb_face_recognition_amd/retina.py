@@ -22,11 +22,18 @@ def remove_prefix(state_dict, prefix):
 
 
 class RetinaFace:
+    """RetinaFace (mobilenet0.25) detector plugin (/root/reference/models/retina_face.py:56-232).
+
+    Limits of the device tables (reference-legal inputs beyond them fail loudly, never truncate): at most 16 384 anchors
+    per frame above `conf_thres` (VNF_E_CAPACITY beyond) and `keep_top_k` <= 768 (rejected at create).
+    Without `checkpoint_path` / `state_dict` the detector is built from the generator's SYNTHETIC weights (no trained
+    checkpoint exists offline; the reference's cfg points at /content/...): boxes are then meaningless -- a
+    RuntimeWarning says so; pass `synthetic=True` (benchmarks, tests) to acknowledge it."""
     channels_subtract = (104, 117, 123)
 
     def __init__(self, backbone_cfg="cfg_mnet", phase="test", backbone_path=None, device="cuda:0", conf_thres=0.02,
                  topk_bf_nms=5000, keep_top_k=750, nms_thres=0.4, vis_thres=0.6, checkpoint_path=None, state_dict=None,
-                 seed=0, max_batch=1, compute_dtype="f32"):
+                 seed=0, max_batch=1, compute_dtype="f32", synthetic=False):
         if backbone_cfg != "cfg_mnet":
             raise NotImplementedError("RetinaFace: only backbone_cfg='cfg_mnet' (mobilenet0.25) is built for MI355X; %r "
                                       "needs the torchvision ResNet-50 download (retina_face.py:84-86)" % (backbone_cfg,))
@@ -53,6 +60,12 @@ class RetinaFace:
         else:
             # no trained checkpoint exists offline (the reference's lives under /content/...): deterministic synthetic weights
             from .weights import generate_state_dict
+            if not synthetic:
+                import warnings
+                warnings.warn("RetinaFace: no checkpoint_path / state_dict given -- running on SYNTHETIC random weights "
+                              "(seed %d); detections are meaningless.  Pass checkpoint_path=... (cfg/detection/"
+                              "retina_face.json) for a trained model, or synthetic=True to silence this." % seed,
+                              RuntimeWarning, stacklevel=2)
             self._sd = generate_state_dict("retina", seed=seed)
 
     def load_model(self, pretrained_path):

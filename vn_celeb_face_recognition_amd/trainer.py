@@ -106,7 +106,11 @@ class TrainableMLP:
         on a CPU tensor would draw them (models/mlp_model.py:12)."""
         b = int(data.shape[0])
         x = data.to(self.device, dtype=torch.float32).contiguous()
-        t = torch.as_tensor(target).to(self.device, dtype=torch.int64).contiguous()
+        th = torch.as_tensor(target).to(dtype=torch.int64)
+        if th.numel() and (int(th.min()) < 0 or int(th.max()) >= self.num_classes):
+            # torch's nll_loss raises on such a label (trainer/classification_trainer.py:22 F.nll_loss)
+            raise IndexError("Target %d is out of bounds." % int(th.max() if int(th.max()) >= self.num_classes else th.min()))
+        t = th.to(self.device).contiguous()
         mask = None
         if train:
             mask = (torch.empty((b, 2048), dtype=torch.float32).bernoulli_(0.5) / 0.5).to(self.device)
