@@ -3,6 +3,7 @@
 #include <new>
 
 #include "engine.h"
+#include <cstdlib>
 
 namespace vnf {
 const char* last_error_cstr();
@@ -53,6 +54,12 @@ int vnf_encoder_create(int arch, const vnf_tensor_desc* weights, int n_weights, 
   e->kind = 1;
   e->arch = arch;
   e->dtype = compute_dtype;  // VNF_F32/BF16/F16/F16X2 == vnf::F32/BF16/F16/F16X2
+  // the encoders keep split-f16 tensors PLANAR (8-channel units [8 hi][8 lo]; three MFMAs per product, split_f16.h);
+  // VNF_SPLIT_LAYOUT=interleaved restores the (hi, lo)-pair layout of the first version (four MFMA-equivalents)
+  if (compute_dtype == VNF_F16X2) {
+    const char* lay = getenv("VNF_SPLIT_LAYOUT");
+    if (!lay || std::string(lay) != "interleaved") e->dtype = F16P;
+  }
   e->max_batch = max_batch;
   (void)hipGetDevice(&e->device);
   WeightMap wm(weights, n_weights);

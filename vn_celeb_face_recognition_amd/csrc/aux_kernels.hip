@@ -12,6 +12,23 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
 
+// planar split-f16 (split_f16.h pf16): 8 consecutive channels = [8 hi halves][8 lo halves], 32 bytes
+__device__ __forceinline__ void store_unit_pf16(void* dst, const float (&v)[8]) {
+  f16x8_t h, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const sf16 s(v[i]);
+    h[i] = s.hi; l[i] = s.lo;
+  }
+  reinterpret_cast<f16x8_t*>(dst)[0] = h;
+  reinterpret_cast<f16x8_t*>(dst)[1] = l;
+}
+__device__ __forceinline__ void load_unit_pf16(const void* src, float (&v)[8]) {
+  const f16x8_t h = reinterpret_cast<const f16x8_t*>(src)[0], l = reinterpret_cast<const f16x8_t*>(src)[1];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)h[i] + (float)l[i];
+}
+
 // ---------------------------------------------------------------- NCHW (n,3,S,S) -> NHWC8
 template <typename TI, typename TO>
 __global__ void pack_input_kernel(const TI* __restrict__ x, TO* __restrict__ y, int n, int hw) {
@@ -19,18 +36,23 @@ __global__ void pack_input_kernel(const TI* __restrict__ x, TO* __restrict__ y, 
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t img = i / hw, p = i - img * hw;
     const TI* src = x + img * 3 * (size_t)hw + p;
-    TO o[8];
-    o[0] = (TO)to_f(src[0]);
-    o[1] = (TO)to_f(src[hw]);
-    o[2] = (TO)to_f(src[2 * (size_t)hw]);
-#pragma unroll
-    for (int c = 3; c < 8; ++c) o[c] = (TO)0.f;
-    TO* dst = y + i * 8;
-    if constexpr (sizeof(TO) == 2) {
-      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
+    if constexpr (sizeof(TO) == sizeof(pf16) && __is_same(TO, pf16)) {
+      const float v[8] = {to_f(src[0]), to_f(src[hw]), to_f(src[2 * (size_t)hw]), 0.f, 0.f, 0.f, 0.f, 0.f};
+      store_unit_pf16(y + i * 8, v);
     } else {
-      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
-      *reinterpret_cast<uint4*>(dst + 4) = *reinterpret_cast<const uint4*>(o + 4);
+      TO o[8];
+      o[0] = (TO)to_f(src[0]);
+      o[1] = (TO)to_f(src[hw]);
+      o[2] = (TO)to_f(src[2 * (size_t)hw]);
+#pragma unroll
+      for (int c = 3; c < 8; ++c) o[c] = (TO)0.f;
+      TO* dst = y + i * 8;
+      if constexpr (sizeof(TO) == 2) {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
+      } else {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
+        *reinterpret_cast<uint4*>(dst + 4) = *reinterpret_cast<const uint4*>(o + 4);
+      }
     }
   }
 }
@@ -45,6 +67,7 @@ static hipError_t pack_dispatch_out(const void* x, void* out, int dtype, int n, 
     case F16: hipLaunchKernelGGL((pack_input_kernel<TI, _Float16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (_Float16*)out, n, hw); break;
     case F32: hipLaunchKernelGGL((pack_input_kernel<TI, float>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (float*)out, n, hw); break;
     case F16X2: hipLaunchKernelGGL((pack_input_kernel<TI, sf16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (sf16*)out, n, hw); break;
+    case F16P: hipLaunchKernelGGL((pack_input_kernel<TI, pf16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (pf16*)out, n, hw); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -92,12 +115,22 @@ __global__ void __launch_bounds__(256) stem_conv1a_kernel(const TI* __restrict__
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = __builtin_elementwise_fma(v2, f2_t{wt[k * 32 + 2 * j], wt[k * 32 + 2 * j + 1]}, acc[j]);
   }
-  TO o[32];
+  if constexpr (__is_same(TO, pf16)) {
 #pragma unroll
-  for (int j = 0; j < 16; ++j) { o[2 * j] = (TO)fmaxf(acc[j][0], 0.f); o[2 * j + 1] = (TO)fmaxf(acc[j][1], 0.f); }
-  uint4* dst = reinterpret_cast<uint4*>(y + (size_t)i * ldy);
+    for (int u = 0; u < 4; ++u) {
+      float v[8];
 #pragma unroll
-  for (int q = 0; q < (int)(32 * sizeof(TO) / 16); ++q) dst[q] = reinterpret_cast<const uint4*>(o)[q];
+      for (int j = 0; j < 4; ++j) { v[2 * j] = fmaxf(acc[4 * u + j][0], 0.f); v[2 * j + 1] = fmaxf(acc[4 * u + j][1], 0.f); }
+      store_unit_pf16(y + (size_t)i * ldy + u * 8, v);
+    }
+  } else {
+    TO o[32];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { o[2 * j] = (TO)fmaxf(acc[j][0], 0.f); o[2 * j + 1] = (TO)fmaxf(acc[j][1], 0.f); }
+    uint4* dst = reinterpret_cast<uint4*>(y + (size_t)i * ldy);
+#pragma unroll
+    for (int q = 0; q < (int)(32 * sizeof(TO) / 16); ++q) dst[q] = reinterpret_cast<const uint4*>(o)[q];
+  }
 }
 
 template <typename TI>
@@ -110,6 +143,7 @@ static hipError_t stem_dispatch_out(const void* x, void* y, int ldy, int dtype, 
     case F16: hipLaunchKernelGGL((stem_conv1a_kernel<TI, _Float16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (_Float16*)y, ldy, n, wt); break;
     case F32: hipLaunchKernelGGL((stem_conv1a_kernel<TI, float>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (float*)y, ldy, n, wt); break;
     case F16X2: hipLaunchKernelGGL((stem_conv1a_kernel<TI, sf16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (sf16*)y, ldy, n, wt); break;
+    case F16P: hipLaunchKernelGGL((stem_conv1a_kernel<TI, pf16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (pf16*)y, ldy, n, wt); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -159,10 +193,39 @@ __global__ void maxpool3s2_kernel(const T* __restrict__ x, int ldx, T* __restric
   }
 }
 
+// planar split-f16: one thread per (pixel, 8-channel unit); max of the recombined values, re-split (exact: the pair
+// of the largest value is reproduced bit for bit)
+__global__ void maxpool3s2_pf16_kernel(const pf16* __restrict__ x, int ldx, pf16* __restrict__ y, int ldy, int n, int H, int W, int C) {
+  const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1, cc = C / 8;
+  const unsigned total = (unsigned)n * Ho * Wo * cc;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned p = i / cc;
+    const int c = (int)(i - p * cc) * 8;
+    const unsigned q = p / Wo;
+    const int wo = (int)(p - q * Wo);
+    const unsigned img = q / Ho;
+    const int ho = (int)(q - img * Ho);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -3.4e38f;
+    const pf16* xi = x + ((size_t)img * H * W + (size_t)(2 * ho) * W + 2 * wo) * ldx + c;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        float v[8];
+        load_unit_pf16(xi + (size_t)(dh * W + dw) * ldx, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    store_unit_pf16(y + (size_t)p * ldy + c, m);
+  }
+}
+
 hipError_t launch_maxpool3s2(const void* x, int ldx, void* y, int ldy, int dtype, int n, int H, int W, int C,
                              hipStream_t s) {
   const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
-  const int ch = 16 / dtype_size(dtype);
+  const int ch = dtype_chan_align(dtype);
   if (C % ch) return hipErrorInvalidValue;
   const size_t total = (size_t)n * Ho * Wo * (C / ch);
   if (total == 0) return hipSuccess;
@@ -173,6 +236,7 @@ hipError_t launch_maxpool3s2(const void* x, int ldx, void* y, int ldy, int dtype
     case F16: hipLaunchKernelGGL(maxpool3s2_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)x, ldx, (_Float16*)y, ldy, n, H, W, C); break;
     case F32: hipLaunchKernelGGL(maxpool3s2_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, n, H, W, C); break;
     case F16X2: hipLaunchKernelGGL(maxpool3s2_kernel<sf16>, dim3(blocks), dim3(256), 0, s, (const sf16*)x, ldx, (sf16*)y, ldy, n, H, W, C); break;
+    case F16P: hipLaunchKernelGGL(maxpool3s2_pf16_kernel, dim3(blocks), dim3(256), 0, s, (const pf16*)x, ldx, (pf16*)y, ldy, n, H, W, C); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -246,10 +310,33 @@ __global__ void avgpool_kernel(const T* __restrict__ x, int ldx, T* __restrict__
   }
 }
 
+__global__ void avgpool_pf16_kernel(const pf16* __restrict__ x, int ldx, pf16* __restrict__ y, int n, int HW, int C) {
+  const size_t total = (size_t)n * (C / 8);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t img = i / (C / 8);
+    const int c = (int)(i - img * (C / 8)) * 8;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < HW; ++p) {
+      float v[8];
+      load_unit_pf16(x + (img * HW + p) * (size_t)ldx + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = s[e] / (float)HW;
+    store_unit_pf16(y + img * C + c, s);
+  }
+}
+
 hipError_t launch_avgpool(const void* x, int ldx, void* y, int dtype, int n, int HW, int C, hipStream_t s) {
   const size_t total = (size_t)n * C;
   if (total == 0) return hipSuccess;
   const int blocks = (int)((total + 255) / 256);
+  if (dtype == F16P) {
+    if (C % 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(avgpool_pf16_kernel, dim3((int)((total / 8 + 255) / 256)), dim3(256), 0, s, (const pf16*)x, ldx, (pf16*)y, n, HW, C);
+    return hipGetLastError();
+  }
   switch (dtype) {
     case BF16: hipLaunchKernelGGL(avgpool_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)x, ldx, (__bf16*)y, n, HW, C); break;
     case F16: hipLaunchKernelGGL(avgpool_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)x, ldx, (_Float16*)y, n, HW, C); break;
@@ -603,10 +690,28 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, int ldx, float* __r
   }
 }
 
+__global__ void nhwc_to_nchw_pf16_kernel(const pf16* __restrict__ x, int ldx, float* __restrict__ y, int n, int HW, int C) {
+  const size_t total = (size_t)n * HW * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const size_t q = i / HW;
+    const int c = (int)(q % C);
+    const size_t img = q / C;
+    // element c of the slice: unit c / 8 (32 bytes), hi half at 2 * (c % 8), lo half 16 bytes further (the slice starts
+    // on a unit boundary)
+    const _Float16* u = reinterpret_cast<const _Float16*>(x + (img * HW + p) * (size_t)ldx + (c & ~7));
+    y[i] = (float)u[c & 7] + (float)u[8 + (c & 7)];
+  }
+}
+
 hipError_t launch_nhwc_to_nchw_f32(const void* x, int ldx, int dtype, float* y, int n, int HW, int C, hipStream_t s) {
   const size_t total = (size_t)n * HW * C;
   if (total == 0) return hipSuccess;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (dtype == F16P) {
+    hipLaunchKernelGGL(nhwc_to_nchw_pf16_kernel, dim3(blocks), dim3(256), 0, s, (const pf16*)x, ldx, y, n, HW, C);
+    return hipGetLastError();
+  }
   switch (dtype) {
     case BF16: hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)x, ldx, y, n, HW, C); break;
     case F16: hipLaunchKernelGGL(nhwc_to_nchw_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)x, ldx, y, n, HW, C); break;

@@ -69,6 +69,34 @@ __device__ __forceinline__ void mma_chunk<sf16>(f32x4_t& acc, const uint4& wf, c
                                                acc, 0, 0, 0);
 }
 
+// ---- planar split-f16 (pf16, split_f16.h): one K tile in LDS = [hi chunk of unit 0..3 | lo chunk of unit 0..3], so the
+// fragment reads of "half" 0 / 1 of a K tile (chunk ks*4 + fgrp) return the hi / lo plane of the lane group's 8 k values
+template <typename T> struct is_planar { static constexpr bool value = false; };
+template <> struct is_planar<pf16> { static constexpr bool value = true; };
+
+// channel (k) index of logical 16-byte chunk `lchunk` (0..7) inside a K tile, and the chunk's extra byte offset
+// inside its 8-channel unit (planar: chunks 4..7 are the lo planes of units 0..3)
+template <typename T> __device__ __forceinline__ int chunk_chan(int lchunk) {
+  if constexpr (is_planar<T>::value) return (lchunk & 3) * 8;
+  else return lchunk * (16 / (int)sizeof(T));
+}
+template <typename T> __device__ __forceinline__ int chunk_byte(int lchunk) {
+  if constexpr (is_planar<T>::value) return (lchunk >> 2) * 16;
+  else return 0;
+}
+
+__device__ __forceinline__ f32x4_t mfma_f16(const uint4& a, const uint4& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+// planar split product of one K tile for one (weight tile, pixel tile): hi.hi' first, then the two cross terms
+__device__ __forceinline__ void mma_hh(f32x4_t& acc, const uint4& wh, const uint4& xh) { acc = mfma_f16(wh, xh, acc); }
+__device__ __forceinline__ void mma_cross(f32x4_t& acc, const uint4& wh, const uint4& wl, const uint4& xh, const uint4& xl) {
+  acc = mfma_f16(wh, xl, acc);
+  acc = mfma_f16(wl, xh, acc);
+}
+template <>
+__device__ __forceinline__ void mma_chunk<pf16>(f32x4_t&, const uint4&, const uint4&) {}  // planar tiles go through mma_hh / mma_cross
+
 template <typename T>
 __device__ __forceinline__ void load8(const char* p, float (&v)[8]);
 template <>
@@ -98,6 +126,13 @@ __device__ __forceinline__ void load8<sf16>(const char* p, float (&v)[8]) {
     v[i] = (float)a[2 * i] + (float)a[2 * i + 1];
     v[4 + i] = (float)b[2 * i] + (float)b[2 * i + 1];
   }
+}
+
+template <>
+__device__ __forceinline__ void load8<pf16>(const char* p, float (&v)[8]) {
+  f16x8_t h = *reinterpret_cast<const f16x8_t*>(p), l = *reinterpret_cast<const f16x8_t*>(p + 16);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)h[i] + (float)l[i];
 }
 
 template <typename T>
@@ -134,6 +169,18 @@ __device__ __forceinline__ void store8<sf16>(char* p, const float (&v)[8]) {
   }
   *reinterpret_cast<f16x8_t*>(p) = a;
   *reinterpret_cast<f16x8_t*>(p + 16) = b;
+}
+
+template <>
+__device__ __forceinline__ void store8<pf16>(char* p, const float (&v)[8]) {
+  f16x8_t h, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const sf16 s(v[i]);
+    h[i] = s.hi; l[i] = s.lo;
+  }
+  *reinterpret_cast<f16x8_t*>(p) = h;
+  *reinterpret_cast<f16x8_t*>(p + 16) = l;
 }
 
 // XCD-aware, bijective block -> tile map: blocks that share an XCD (same blockIdx % 8) walk

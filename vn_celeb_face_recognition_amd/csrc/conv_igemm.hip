@@ -32,6 +32,7 @@
 // dtype paths: bf16 / f16 -> v_mfma_f32_16x16x32_{bf16,f16}; f32 -> v_mfma_f32_16x16x4_f32
 // (exact f32 FMA chain; the <=1e-4 parity path).
 #include <cstdlib>
+#include <type_traits>
 
 #include "block35.h"
 #include "conv_device.h"
@@ -65,6 +66,29 @@ template <typename T, int TM, int TN>
 __device__ __forceinline__ void tile_mma(const char* sA, const char* sB, int arow0, int brow0, int frow, int fgrp,
                                          int kleft, f32x4_t (&acc)[TM][TN]) {
   constexpr int BKE = 128 / (int)sizeof(T);
+  if constexpr (is_planar<T>::value) {
+    uint4 xh[TM], xl[TM], wh[TN], wl[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = arow0 + i * 16 + frow;
+      xh[i] = *reinterpret_cast<const uint4*>(sA + row * 128 + ((fgrp ^ (row & 7)) << 4));
+      xl[i] = *reinterpret_cast<const uint4*>(sA + row * 128 + (((4 + fgrp) ^ (row & 7)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = brow0 + j * 16 + frow;
+      wh[j] = *reinterpret_cast<const uint4*>(sB + row * 128 + ((fgrp ^ (row & 7)) << 4));
+      wl[j] = *reinterpret_cast<const uint4*>(sB + row * 128 + (((4 + fgrp) ^ (row & 7)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        mma_hh(acc[i][j], wh[j], xh[i]);
+        mma_cross(acc[i][j], wh[j], wl[j], xh[i], xl[i]);
+      }
+    return;
+  }
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     if (ks * (BKE / 2) < kleft) {
@@ -124,7 +148,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const KArgs
   // issue() -- issue() is called with consecutive kt -- instead of looked up in the layer's gather table, so the
   // prologue has no table load and no barrier before the first DMA (the table's round trip was ~1.5 k cycles of
   // every workgroup; most launches of the inception blocks only live ~10 k).
-  int g_c = lchunk * CH, g_kh = 0, g_kw = 0;
+  int g_c = chunk_chan<T>(lchunk), g_kh = 0, g_kw = 0;
+  const int g_byte = chunk_byte<T>(lchunk);  // planar split-f16: the lo plane sits 16 bytes into its 8-channel unit
   auto g_norm = [&]() {
     while (g_c >= a.Cin) {
       g_c -= a.Cin;
@@ -140,7 +165,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const KArgs
     for (int p = 0; p < AP; ++p) {
       const int hi = ahi[p] + g_kh, wi = awi[p] + g_kw;
       const bool ok = kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-      const char* src = ok ? a.x + (size_t)(abase[p] + ex) * ES : a.zero;
+      const char* src = ok ? a.x + (size_t)(abase[p] + ex) * ES + g_byte : a.zero;
       glds16(src, sbase + p * (NW * 1024));
     }
 #pragma unroll
@@ -179,8 +204,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const KArgs
 #pragma unroll
       for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], wf[ks][j], xf[ks][i]);
   };
-  bool pend = false;  // second half of the previous K tile read but not yet multiplied
-  for (int kt = 0; kt < nkt; ++kt) {
+  auto sync_tile = [&](int kt) {
     // tile kt has landed once at most the S-2 younger tiles of this wave are still in flight
     if (kt + S - 2 < nkt)
       wait_dma_and_barrier<(S - 2) * L>();
@@ -188,13 +212,71 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const KArgs
       wait_dma_and_barrier<0>();
     // every wave's pieces of tile kt have landed; stage (kt-1)%S is free for tile kt+S-1
     if (kt + S - 1 < nkt) issue(kt + S - 1);
-    read_frags(kt, 0);
+  };
+  if constexpr (is_planar<T>::value) {
+    // planar split-f16: "half" 0 of a K tile is the hi plane, half 1 the lo plane of the same 32 k values.  Per tile
+    // hi.hi' (needs the hi fragments only) and the two cross terms; the cross terms of tile kt-1 run under the hi reads of
+    // tile kt, so the hi fragments are double-buffered (static indices: the loop is unrolled by two).
+    uint4 xh[2][TM], wh[2][TN];
+    auto rd = [&](int kt, int ks, uint4 (&x)[TM], uint4 (&w)[TN]) {
+      const char* sA = smem + (kt % S) * STAGE;
+      const char* sB = sA + BM * 128;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 16 + frow;
+        x[i] = *reinterpret_cast<const uint4*>(sA + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WTN + j * 16 + frow;
+        w[j] = *reinterpret_cast<const uint4*>(sB + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+      }
+    };
+    auto step = [&](auto P, int kt) {
+      constexpr int c = decltype(P)::value;
+      sync_tile(kt);
+      rd(kt, 0, xh[c], wh[c]);
+      if (kt > 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) mma_cross(acc[i][j], wh[c ^ 1][j], wf[1][j], xh[c ^ 1][i], xf[1][i]);
+      }
+      rd(kt, 1, xf[1], wf[1]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_hh(acc[i][j], wh[c][j], xh[c][i]);
+    };
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+      step(std::integral_constant<int, 0>{}, kt);
+      step(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    if (kt < nkt) {
+      step(std::integral_constant<int, 0>{}, kt);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_cross(acc[i][j], wh[0][j], wf[1][j], xh[0][i], xf[1][i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_cross(acc[i][j], wh[1][j], wf[1][j], xh[1][i], xf[1][i]);
+    }
+  } else {
+    bool pend = false;  // second half of the previous K tile read but not yet multiplied
+    for (int kt = 0; kt < nkt; ++kt) {
+      sync_tile(kt);
+      read_frags(kt, 0);
+      if (pend) mma(1);
+      pend = BKE / 2 < a.K - kt * BKE;
+      if (pend) read_frags(kt, 1);
+      mma(0);
+    }
     if (pend) mma(1);
-    pend = BKE / 2 < a.K - kt * BKE;
-    if (pend) read_frags(kt, 1);
-    mma(0);
   }
-  if (pend) mma(1);
   __syncthreads();
   conv_epilogue<T, BM, BN, WM, WN, S * STAGE>(a, acc, smem, m0, n0);
 }
@@ -450,6 +532,7 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t s) {
     case F16: return launch_typed<_Float16>(a, k, s);
     case F32: return launch_typed<float>(a, k, s);
     case F16X2: return launch_typed<sf16>(a, k, s);
+    case F16P: return launch_typed<pf16>(a, k, s);
   }
   return hipErrorInvalidValue;
 }

@@ -21,6 +21,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <type_traits>
 
 #include "conv_device.h"
 
@@ -58,20 +59,27 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_patch_kernel(const KArgs a) 
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
   const unsigned lds_patch = lds0 + (unsigned)(S * STAGE + ptab_bytes + 16);
 
+  // Planar split-f16: the patch is TWO pixel-major images, the hi planes of every 8-channel unit and -- one whole number
+  // of DMA pieces further on -- the lo planes, each with one 16-byte slot per unit: the four lane groups of a fragment
+  // read then take consecutive slots, as for the other dtypes (the bank argument above), instead of every second one.
+  constexpr bool PL = is_planar<T>::value;
+  const int npieces = (nslots + 63) >> 6;          // DMA pieces (1 KiB) per plane
+  const int plane_bytes = npieces * 1024;
   // k-chunk -> byte offset inside the patch relative to the pixel's base (-1: K padding)
   for (int i = tid; i < nkt * 8; i += NT) {
     const int4 e = a.ktab[i];
-    const int cc = (e.x - (e.y * a.W + e.z) * a.ldx) / CH;
-    sP[i] = e.w ? ((e.y * a.Wp + e.z) * a.pp + cc) * 16 : -1;
+    const int cc = (e.x - (e.y * a.W + e.z) * a.ldx) / CH;   // 16-byte chunk inside the pixel (planar: 2 * unit + plane)
+    const int slot = PL ? (cc >> 1) : cc, plane = PL ? (cc & 1) : 0;
+    sP[i] = e.w ? ((e.y * a.Wp + e.z) * a.pp + slot) * 16 + plane * plane_bytes : -1;
   }
   if (tid < 4) reinterpret_cast<int*>(zslot)[tid] = 0;
 
   // the patch: one 1-KiB DMA piece per wave instruction, lane-linear in LDS
   {
-    const int cpb = a.Cin / CH;
-    const int npieces = (nslots + 63) >> 6;
-    for (int pc = wave; pc < npieces; pc += NW) {
-      const int s = pc * 64 + lane;
+    const int cpb = PL ? a.Cin / 8 : a.Cin / CH;
+    for (int pc = wave; pc < (PL ? 2 : 1) * npieces; pc += NW) {
+      const int plane = pc >= npieces ? 1 : 0;
+      const int s = (pc - plane * npieces) * 64 + lane;
       const char* src = a.zero;
       if (s < nslots) {
         const int p = s / a.pp, c = s - p * a.pp;
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_patch_kernel(const KArgs a) 
         const int v = v0 + py, n = v / a.Hv;
         const int iy = v - n * a.Hv - a.ph, ix = px - a.pw;
         if (c < cpb && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-          src = a.x + ((size_t)((n * a.H + iy) * a.W + ix) * a.ldx) * ES + c * 16;
+          src = a.x + ((size_t)((n * a.H + iy) * a.W + ix) * a.ldx) * ES + (PL ? c * 32 + plane * 16 : c * 16);
       }
       glds16(src, __builtin_amdgcn_readfirstlane(lds_patch + (unsigned)pc * 1024u));
     }
@@ -153,9 +161,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_patch_kernel(const KArgs a) 
 #pragma unroll
       for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], wf[ks][j], xf[ks][i]);
   };
-  bool pend = false;
   int t0 = 0, t1 = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
+  auto sync_tile = [&](int kt) {
     // the patch pieces are older than every weight piece, so the first wait covers them too
     if (kt + S - 2 < nkt)
       wait_ring();
@@ -163,15 +170,69 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_patch_kernel(const KArgs a) 
       wait_dma_and_barrier<0>();
     if (kt + S - 1 < nkt) issue(kt + S - 1);
     if (kt == 0) { t0 = sP[fgrp]; t1 = sP[4 + fgrp]; }
-    read_frags(kt, 0, t0);
+  };
+  if constexpr (is_planar<T>::value) {
+    // planar split-f16 (see conv_igemm.hip): half 0 / 1 of a K tile = hi / lo plane; hi fragments double-buffered
+    uint4 xh[2][TM], wh[2][TN];
+    auto rd = [&](int kt, int ks, int t, uint4 (&x)[TM], uint4 (&w)[TN]) {
+      const char* sB = smem + (kt % S) * STAGE;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) x[i] = *reinterpret_cast<const uint4*>(patch + (t >= 0 ? pb[i] + t : -16));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WTN + j * 16 + frow;
+        w[j] = *reinterpret_cast<const uint4*>(sB + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+      }
+    };
+    auto step = [&](auto P, int kt) {
+      constexpr int c = decltype(P)::value;
+      sync_tile(kt);
+      rd(kt, 0, t0, xh[c], wh[c]);
+      if (kt > 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) mma_cross(acc[i][j], wh[c ^ 1][j], wf[1][j], xh[c ^ 1][i], xf[1][i]);
+      }
+      rd(kt, 1, t1, xf[1], wf[1]);
+      t0 = sP[(kt + 1) * 8 + fgrp];  // one row of slack behind the table
+      t1 = sP[(kt + 1) * 8 + 4 + fgrp];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_hh(acc[i][j], wh[c][j], xh[c][i]);
+    };
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+      step(std::integral_constant<int, 0>{}, kt);
+      step(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    if (kt < nkt) {
+      step(std::integral_constant<int, 0>{}, kt);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_cross(acc[i][j], wh[0][j], wf[1][j], xh[0][i], xf[1][i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_cross(acc[i][j], wh[1][j], wf[1][j], xh[1][i], xf[1][i]);
+    }
+  } else {
+    bool pend = false;
+    for (int kt = 0; kt < nkt; ++kt) {
+      sync_tile(kt);
+      read_frags(kt, 0, t0);
+      if (pend) mma(1);
+      pend = BKE / 2 < a.K - kt * BKE;
+      if (pend) read_frags(kt, 1, t1);
+      t0 = sP[(kt + 1) * 8 + fgrp];  // one row of slack behind the table
+      t1 = sP[(kt + 1) * 8 + 4 + fgrp];
+      mma(0);
+    }
     if (pend) mma(1);
-    pend = BKE / 2 < a.K - kt * BKE;
-    if (pend) read_frags(kt, 1, t1);
-    t0 = sP[(kt + 1) * 8 + fgrp];  // one row of slack behind the table
-    t1 = sP[(kt + 1) * 8 + 4 + fgrp];
-    mma(0);
   }
-  if (pend) mma(1);
   __syncthreads();
   conv_epilogue<T, BM, BN, WM, WN, EPI>(a, acc, smem, m0, n0);
 }
@@ -213,7 +274,8 @@ static int patch_rows_max(int Wo, int Ho, int KH, int BM) {
 struct PatchGeom { int pp, Wp, Hv, patch_bytes, lds; };
 
 static bool patch_geom(const ConvArgs& a, const PatchCfg& c, PatchGeom& g) {
-  const int es = dtype_size(a.dtype), ch = 16 / es;
+  const int es = dtype_size(a.dtype), ch = dtype_chan_align(a.dtype);   // slots per pixel: 16-byte chunks (planar: per plane)
+  const int planes = a.dtype == F16P ? 2 : 1;
   if (a.sh != 1 || a.sw != 1 || a.Cin % ch || a.Ho != a.H + 2 * a.ph - a.KH + 1 || a.Wo != a.W + 2 * a.pw - a.KW + 1)
     return false;
   g.pp = a.Cin / ch;
@@ -221,8 +283,8 @@ static bool patch_geom(const ConvArgs& a, const PatchCfg& c, PatchGeom& g) {
   g.Wp = a.W + 2 * a.pw;
   g.Hv = a.H + 2 * a.ph;
   const long long slots = (long long)patch_rows_max(a.Wo, a.Ho, a.KH, c.bm) * g.Wp * g.pp;
-  if (slots * 16 > 160 * 1024) return false;
-  g.patch_bytes = (int)((slots * 16 + 1023) / 1024 * 1024);
+  if (slots * 16 * planes > 160 * 1024) return false;
+  g.patch_bytes = (int)((slots * 16 + 1023) / 1024 * 1024) * planes;
   const int nkt = a.Kpad / (128 / es);
   int lds = c.s * c.bn * 128 + (((nkt + 1) * 8 * 4 + 15) & ~15) + 16 + g.patch_bytes;
   const int epi = patch_epi_bytes(c.bm, c.bn, c.wm);
@@ -298,6 +360,7 @@ hipError_t launch_patch(const ConvArgs& a, const KArgs& k, int pcfg, hipStream_t
     case F16: return launch_patch_typed<_Float16>(pcfg, kk, g.lds, s);
     case F32: return launch_patch_typed<float>(pcfg, kk, g.lds, s);
     case F16X2: return launch_patch_typed<sf16>(pcfg, kk, g.lds, s);
+    case F16P: return launch_patch_typed<pf16>(pcfg, kk, g.lds, s);
   }
   return hipErrorInvalidValue;
 }

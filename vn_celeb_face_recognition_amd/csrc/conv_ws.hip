@@ -15,6 +15,7 @@
 // ring kernel, so results are bit-identical to it.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv_device.h"
 
@@ -154,6 +155,68 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_ws_kernel(const
 #pragma unroll
       for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], wf[fs][j], xf[fs][i]);
   };
+  if constexpr (is_planar<T>::value) {
+    // planar split-f16 (see conv_igemm.hip): half 0 / 1 of a K tile = hi / lo plane of the same 32 k values
+    uint4 xh[NF][TM], wh[NF][TN], xl[TM], wl[TN];
+    auto rd = [&](int kt, int ks, uint4 (&x)[TM], uint4 (&w)[TN]) {
+      const char* sA = smem + (kt % S) * STAGE;
+      const char* sB = sA + BM * 128;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 16 + frow;
+        x[i] = *reinterpret_cast<const uint4*>(sA + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WTN + j * 16 + frow;
+        w[j] = *reinterpret_cast<const uint4*>(sB + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+      }
+    };
+    auto cross = [&](uint4 (&x)[TM], uint4 (&w)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_cross(acc[i][j], w[j], wl[j], x[i], xl[i]);
+    };
+    auto hh = [&](uint4 (&x)[TM], uint4 (&w)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_hh(acc[i][j], w[j], x[i]);
+    };
+    if constexpr (PIPE) {
+      auto step = [&](auto P, int kt) {
+        constexpr int c = decltype(P)::value;
+        wait_dma_and_barrier<0>();
+        rd(kt, 0, xh[c], wh[c]);
+        if (kt > 0) cross(xh[c ^ 1], wh[c ^ 1]);
+        rd(kt, 1, xl, wl);
+        hh(xh[c], wh[c]);
+      };
+      int kt = 0;
+      for (; kt + 1 < nkt; kt += 2) {
+        step(std::integral_constant<int, 0>{}, kt);
+        step(std::integral_constant<int, 1>{}, kt + 1);
+      }
+      if (kt < nkt) {
+        step(std::integral_constant<int, 0>{}, kt);
+        cross(xh[0], wh[0]);
+      } else {
+        cross(xh[NF - 1], wh[NF - 1]);
+      }
+    } else {
+      for (int kt = 0; kt < nkt; ++kt) {
+        wait_dma_and_barrier<0>();
+        rd(kt, 0, xh[0], wh[0]);
+        rd(kt, 1, xl, wl);
+        hh(xh[0], wh[0]);
+        cross(xh[0], wh[0]);
+      }
+    }
+    __syncthreads();
+    conv_epilogue<T, BM, BN, WM, WN, EPI_LDS>(a, acc, smem, m0, n0);
+    return;
+  }
   bool pend = false;
   for (int kt = 0; kt < nkt; ++kt) {
     if constexpr (DBG) {
@@ -292,6 +355,7 @@ hipError_t launch_ws(const ConvArgs& a, const KArgs& k, int wcfg, hipStream_t s)
     case F16: return launch_ws_typed<_Float16>(wcfg, k, s);
     case F32: return launch_ws_typed<float>(wcfg, k, s);
     case F16X2: return launch_ws_typed<sf16>(wcfg, k, s);
+    case F16P: return launch_ws_typed<pf16>(wcfg, k, s);
   }
   return hipErrorInvalidValue;
 }

@@ -82,6 +82,16 @@ void convert_to(int dtype, const float* src, void* dst, size_t n) {
   } else if (dtype == F16X2) {
     sf16* d = (sf16*)dst;
     for (size_t i = 0; i < n; ++i) d[i] = sf16(src[i]);
+  } else if (dtype == F16P) {
+    // planar split-f16 WEIGHTS: per K tile of 32 k values [32 hi][32 lo] -- the 128-byte LDS row of a K tile is its
+    // four hi chunks followed by its four lo chunks (conv_device.h); n is a whole number of K tiles
+    _Float16* d = (_Float16*)dst;
+    for (size_t t = 0; t + 32 <= n; t += 32)
+      for (int i = 0; i < 32; ++i) {
+        const sf16 v(src[t + i]);
+        d[2 * t + i] = v.hi;
+        d[2 * t + 32 + i] = v.lo;
+      }
   } else {
     _Float16* d = (_Float16*)dst;
     for (size_t i = 0; i < n; ++i) d[i] = (_Float16)src[i];
@@ -404,7 +414,8 @@ struct ConvSpec {
 };
 
 static int add_conv(Encoder& e, const ConvSpec& s) {
-  const int es = dtype_size(e.dtype), ch = 16 / es, bke = 128 / es;
+  const int es = dtype_size(e.dtype), ch = dtype_chan_align(e.dtype), bke = 128 / es;
+  const bool planar = e.dtype == F16P;
   const Buf& xb = e.bufs[s.x_buf];
   ConvLayer L;
   L.name = s.name;
@@ -469,12 +480,15 @@ static int add_conv(Encoder& e, const ConvSpec& s) {
   L.w = e.upload(wdev.data(), wdev.size());
   L.bias = (float*)e.upload(bias.data(), bias.size() * 4);
   if (has_slope) L.slope = (float*)e.upload(slope.data(), slope.size() * 4);
-  std::vector<int4> kt(L.Kpad / ch);
-  for (int kc = 0; kc < L.Kpad / ch; ++kc) {
-    const int k = kc * ch;
+  // gather table: one entry per 16-byte chunk of the K-tile image, 8 per K tile.  Planar split-f16: chunk q of a tile
+  // is the hi (q < 4) or lo (q >= 4) plane of the 8-channel unit q & 3, 16 bytes (4 elements) into the unit for lo.
+  std::vector<int4> kt(L.Kpad / bke * 8);
+  for (int kc = 0; kc < (int)kt.size(); ++kc) {
+    const int q = kc & 7;
+    const int k = planar ? (kc >> 3) * bke + (q & 3) * 8 : kc * (16 / es);
     if (k < L.K) {
       const int tap = k / s.cin_pad, c = k % s.cin_pad, kh = tap / s.KW, kw = tap % s.KW;
-      kt[kc] = int4{(kh * L.W + kw) * xb.C + c, kh, kw, 1};
+      kt[kc] = int4{(kh * L.W + kw) * xb.C + c + (planar ? (q >> 2) * 4 : 0), kh, kw, 1};
     } else {
       kt[kc] = int4{0, 0, 0, 0};
     }
@@ -496,7 +510,8 @@ static int add_conv(Encoder& e, const ConvSpec& s) {
   L.res_buf = s.res_buf; L.res_coff = s.res_coff;
   L.act = s.act; L.out_f32 = s.out_f32;
   L.macs_alg = (double)L.Ho * L.Wo * cout_logical * (double)(s.KH * s.KW * s.cin);
-  const int k32 = (L.K + bke / 2 - 1) / (bke / 2) * (bke / 2);
+  const int kstep = planar ? bke : bke / 2;   // k values one MFMA group consumes
+  const int k32 = (L.K + kstep - 1) / kstep * kstep;
   L.macs_exec = (double)L.Ho * L.Wo * cout * (double)k32;
   e.convs.push_back(L);
   Op op; op.kind = Op::CONV; op.a = (int)e.convs.size() - 1;

@@ -6,8 +6,11 @@
 namespace vnf {
 
 // F16X2: split-f16 (hi, lo) pairs, split_f16.h -- fp32-class accuracy on the 16-bit MFMA (ids follow include/vnface.h)
-enum DType { F32 = 0, BF16 = 1, F16 = 2, F16X2 = 5 };
-inline int dtype_size(int dt) { return (dt == F32 || dt == F16X2) ? 4 : 2; }
+// F16P: planar split-f16 (8-channel units [8 hi][8 lo], three MFMAs per product): what the ENCODERS run when the caller
+// asks for VNF_F16X2; F16X2 itself (interleaved pairs) stays the storage of the R-Net / O-Net / RetinaFace plans
+enum DType { F32 = 0, BF16 = 1, F16 = 2, F16X2 = 5, F16P = 6 };
+inline int dtype_size(int dt) { return (dt == F32 || dt == F16X2 || dt == F16P) ? 4 : 2; }
+inline int dtype_chan_align(int dt) { return dt == F16P ? 8 : 16 / dtype_size(dt); }   // channel granularity of slices / gathers
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_PRELU = 2 };
 

@@ -18,4 +18,17 @@ struct sf16 {
 };
 static_assert(sizeof(sf16) == 4, "sf16 is one dword");
 
+// Planar split-f16 ("F16P", the encoders' f16x2 storage): the same (hi, lo) halves, but laid out per group of 8
+// consecutive channels (or k values) as [hi0 .. hi7][lo0 .. lo7] -- 32 bytes, the hi plane and the lo plane each one
+// 16-byte MFMA operand chunk.  The product of two such tensors is then three plain MFMAs on chunks as they are loaded,
+//     W_hi . X_hi  +  W_hi . X_lo  +  W_lo . X_hi          (lo . lo' is below 2^-22 of the product and is dropped)
+// with no lane or register shuffling at all (the interleaved sf16 form needs four MFMA-equivalents and a rotation of
+// every activation dword).  pf16 is a TAG for templates: sizeof == 4 bytes per value so that element offsets,
+// strides and buffer sizes are those of any 4-byte dtype; single elements are never addressed through it -- tensors
+// are read and written in 8-channel units (load8 / store8), channel counts and offsets are multiples of 8.
+struct pf16 {
+  unsigned bits;
+};
+static_assert(sizeof(pf16) == 4, "pf16 stands for 4 bytes per value");
+
 }  // namespace vnf
