@@ -208,10 +208,10 @@ def test_ir100_split_f16_matches_reference_golden():
     assert err.max() <= 1e-4, err
 
 
-@pytest.mark.parametrize("dt,tol", [("bf16", 2.5e-2), ("f16", 3e-3)])
+@pytest.mark.parametrize("dt,tol", [("bf16", 2.5e-2), ("f16", 3e-3), ("f16x2", 2e-5)])
 def test_persistent_block17_trunk_kernel_matches_the_unfused_plan_and_the_oracle(irv1_sd, monkeypatch, dt, tol):
     """repeat_2 (10 x Block17, inception_resnet_v1.py:70-95) runs as ONE persistent kernel on the 16-bit paths
-    (trunk17.hip: residual trunk in fp32 registers, intermediates in LDS).  Against the fp32 oracle's stage taps it
+    (trunk17.hip; trunk17s.hip for the planar split-f16 dtype: residual trunk in fp32 registers, intermediates in LDS).  Against the fp32 oracle's stage taps it
     must be at least as close as the unfused per-convolution plan (VNF_FUSE=0), which rounds the trunk to 16 bits after
     every block; the two plans must agree with each other to the storage precision."""
     from vn_celeb_face_recognition_amd.models import InceptionResnetV1
@@ -234,11 +234,11 @@ def test_persistent_block17_trunk_kernel_matches_the_unfused_plan_and_the_oracle
     rp = np.linalg.norm(tp["repeat_2"] - want) / np.linalg.norm(want)
     print("%s repeat_2 tap vs fp32 oracle: fused max %.3e rel-L2 %.3e | unfused max %.3e rel-L2 %.3e" % (dt, ef, rf, ep, rp))
     assert ef <= tol and rf <= tol
-    assert rf <= rp * 1.05                                          # fp32 trunk: not worse than the 16-bit trunk
+    assert rf <= max(rp * 1.05, 3e-6)                               # fp32 trunk: not worse than the 16-bit trunk (f16x2: both at fp32 noise)
     assert np.abs(tf["repeat_2"] - tp["repeat_2"]).max() / scale <= 2 * tol
     e_f, e_p = np.linalg.norm(yf - ref, axis=1).max(), np.linalg.norm(yp - ref, axis=1).max()
     print("%s embedding L2 vs fp32 oracle: fused %.3e unfused %.3e" % (dt, e_f, e_p))
-    assert e_f <= max(6e-2 if dt == "bf16" else 8e-3, e_p * 1.2)
+    assert e_f <= (1e-4 if dt == "f16x2" else max(6e-2 if dt == "bf16" else 8e-3, e_p * 1.2))
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])

@@ -282,7 +282,8 @@ int Encoder::prepare_fused() {
   const int enabled = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 15;
   for (FusedStack& f : fused) {
     f.active = false;
-    if (!enabled || (dtype != BF16 && dtype != F16) || f.nblocks < 1 || f.nblocks > T17_MAX_BLOCKS) continue;
+    if (!enabled || (dtype != BF16 && dtype != F16 && dtype != F16P) || f.nblocks < 1 || f.nblocks > T17_MAX_BLOCKS) continue;
+    if (dtype == F16P && f.kind != 17) continue;   // planar split-f16: the Block17 trunk has a fused twin (trunk17s.hip)
     if (f.kind == 2) {
       if (!(enabled & 4)) continue;
       const ConvLayer& c2a = convs[f.conv0];
@@ -354,10 +355,10 @@ int Encoder::prepare_fused() {
         f.macs_alg += L.macs_alg;
       }
     if (!ok) return fail(VNF_E_INVALID, "fused Block17 stack: unexpected layer shapes");
-    f.wstream = dalloc(trunk17_stream_bytes(f.nblocks));
+    f.wstream = dalloc(dtype == F16P ? trunk17s_stream_bytes(f.nblocks) : trunk17_stream_bytes(f.nblocks));
     f.bias = (float*)upload(bias.data(), bias.size() * 4);
     if (!f.wstream || !f.bias) return VNF_E_HIP;
-    VNF_HIP(trunk17_repack(pk, f.wstream, 0));
+    VNF_HIP(dtype == F16P ? trunk17s_repack(pk, f.wstream, 0) : trunk17_repack(pk, f.wstream, 0));
     VNF_HIP(hipDeviceSynchronize());
     f.active = true;
   }
@@ -1368,7 +1369,7 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
           ta.y = ob.ptr + (size_t)n0 * ob.elems_per_image() * es;
           ta.ldx = ib.C; ta.ldy = ob.C; ta.n = nn; ta.nblocks = fs->nblocks;
           ta.wstream = fs->wstream; ta.bias = fs->bias;
-          hipError_t err = launch_trunk17(ta, dtype, s);
+          hipError_t err = dtype == F16P ? launch_trunk17s(ta, s) : launch_trunk17(ta, dtype, s);
           if (err != hipSuccess) return fail(VNF_E_HIP, std::string("fused Block17 stack: ") + hipGetErrorString(err));
           oi = fs->last - 1;
           continue;

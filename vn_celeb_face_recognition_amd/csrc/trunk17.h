@@ -24,6 +24,11 @@ struct Trunk17Pack {
   int nblocks;
 };
 
+// planar split-f16 twin (trunk17s.hip): x / y are F16P tensors (4 bytes per value), the pack's weights F16P-packed
+size_t trunk17s_stream_bytes(int nblocks);
+hipError_t trunk17s_repack(const Trunk17Pack& p, void* out, hipStream_t s);
+hipError_t launch_trunk17s(const Trunk17Args& a, hipStream_t s);
+
 size_t trunk17_stream_bytes(int nblocks);
 hipError_t trunk17_repack(const Trunk17Pack& p, void* out, hipStream_t s);
 hipError_t launch_trunk17(const Trunk17Args& a, int dtype, hipStream_t s);
