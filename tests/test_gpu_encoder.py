@@ -328,3 +328,31 @@ def test_taps_inside_an_active_fused_kernel_are_refused(monkeypatch):
     for name, c in (("conv2d_1a", 32), ("conv2d_3b", 80), ("repeat_1", 256), ("repeat_2", 896)):
         t = m.tap(name, 2)
         assert t.shape[:2] == (2, c) and np.isfinite(t).all() and np.abs(t).max() > 0
+
+
+@pytest.mark.parametrize("n", [1, 7])
+def test_fused_block35_split_f16_matches_the_five_launch_plan_and_the_oracle(irv1_sd, monkeypatch, n):
+    """block35s.hip: one launch per Block35 in the planar split-f16 dtype (branch outputs stay in registers as MFMA B
+    fragments in a permuted k order, reduce weights ride the x ring).  Same products as the plan's five convolutions but
+    a different summation order inside the up convolution's 32-deep steps: fp32-noise agreement with the unfused plan,
+    and the 1e-4 bars against the oracle."""
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    from oracle import irv1
+    x = seeded_normal((n, 3, 160, 160), 71 + n)
+    taps = {}
+    ref = irv1.irv1_forward(irv1_sd, x, taps=taps).numpy()
+    monkeypatch.setenv("VNF_FUSE", "2")      # Block35 only
+    fused = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype="f16x2", max_batch=n).eval()
+    yf = fused(x.cuda()).cpu().numpy()
+    a4, r1 = fused.tap("conv2d_4b", n), fused.tap("repeat_1", n)
+    monkeypatch.setenv("VNF_FUSE", "0")
+    plain = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype="f16x2", max_batch=n).eval()
+    yp = plain(x.cuda()).cpu().numpy()
+    assert np.array_equal(a4, plain.tap("conv2d_4b", n))           # same input to the blocks
+    want_p, want_o = plain.tap("repeat_1", n), taps["repeat_1"].numpy()
+    scale = np.abs(want_o).max()
+    assert np.isfinite(r1).all()
+    e_plan, e_orc = np.abs(r1 - want_p).max() / scale, np.abs(r1 - want_o).max() / scale
+    print("block35s repeat_1: vs unfused plan %.2e, vs oracle %.2e (unfused vs oracle %.2e)" % (e_plan, e_orc, np.abs(want_p - want_o).max() / scale))
+    assert e_plan <= 2e-6 and e_orc <= 1e-5
+    assert np.linalg.norm(yf - ref, axis=1).max() <= 1e-4 and np.linalg.norm(yf - yp, axis=1).max() <= 5e-6

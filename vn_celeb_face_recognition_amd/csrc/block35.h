@@ -26,6 +26,11 @@ struct Block35Pack {   // packed engine weights [rows][kpad] (k = (kh, kw, c)) o
   const float* bias;   // device [B35_BIAS]: the five convolutions' biases in that order
 };
 
+// planar split-f16 twin (block35s.hip): x / y are F16P tensors, the pack's weights F16P-packed; 300 fragments + 2 KiB biases
+constexpr int B35S_WIMG_BYTES = (300 + 2) * 1024;
+hipError_t block35s_repack(const Block35Pack& p, void* out, hipStream_t s);
+hipError_t launch_block35s(const Block35Args& a, hipStream_t s);
+
 hipError_t block35_repack(const Block35Pack& p, void* out, hipStream_t s);
 hipError_t launch_block35(const Block35Args& a, int dtype, hipStream_t s);
 const char* conv_zero_page();  // conv_igemm.hip: per-device page of zero bytes

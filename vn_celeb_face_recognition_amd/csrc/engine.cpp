@@ -283,7 +283,7 @@ int Encoder::prepare_fused() {
   for (FusedStack& f : fused) {
     f.active = false;
     if (!enabled || (dtype != BF16 && dtype != F16 && dtype != F16P) || f.nblocks < 1 || f.nblocks > T17_MAX_BLOCKS) continue;
-    if (dtype == F16P && f.kind != 17) continue;   // planar split-f16: the Block17 trunk has a fused twin (trunk17s.hip)
+    if (dtype == F16P && f.kind == 2) continue;   // planar split-f16: Block17 trunk and Block35 have fused twins (trunk17s / block35s.hip)
     if (f.kind == 2) {
       if (!(enabled & 4)) continue;
       const ConvLayer& c2a = convs[f.conv0];
@@ -317,7 +317,8 @@ int Encoder::prepare_fused() {
       if (!(enabled & 2)) continue;
       std::vector<float> bias((size_t)f.nblocks * B35_BIAS, 0.f);
       static const int rows[5] = {96, 32, 32, 32, 256}, ks[5] = {256, 288, 288, 288, 96}, boff[5] = {0, 96, 128, 160, 192};
-      f.wstream = dalloc((size_t)f.nblocks * B35_WIMG_BYTES);
+      const size_t wimg_bytes = dtype == F16P ? B35S_WIMG_BYTES : B35_WIMG_BYTES;
+      f.wstream = dalloc((size_t)f.nblocks * wimg_bytes);
       f.bias = (float*)dalloc(bias.size() * 4);
       if (!f.wstream || !f.bias) return VNF_E_HIP;
       for (int b = 0; b < f.nblocks; ++b) {
@@ -332,7 +333,8 @@ int Encoder::prepare_fused() {
           f.macs_alg += L.macs_alg;
         }
         VNF_HIP(hipMemcpy(f.bias + (size_t)b * B35_BIAS, &bias[(size_t)b * B35_BIAS], (size_t)B35_BIAS * 4, hipMemcpyHostToDevice));
-        VNF_HIP(block35_repack(pk, (char*)f.wstream + (size_t)b * B35_WIMG_BYTES, 0));
+        VNF_HIP(dtype == F16P ? block35s_repack(pk, (char*)f.wstream + (size_t)b * wimg_bytes, 0)
+                              : block35_repack(pk, (char*)f.wstream + (size_t)b * wimg_bytes, 0));
       }
       VNF_HIP(hipDeviceSynchronize());
       f.active = true;
@@ -1353,9 +1355,9 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
             ba.x = ib.ptr + (size_t)n0 * ib.elems_per_image() * es;
             ba.y = ob.ptr + (size_t)n0 * ob.elems_per_image() * es;
             ba.ldx = ib.C; ba.ldy = ob.C; ba.n = nn;
-            ba.wimg = (const char*)fs->wstream + (size_t)b * B35_WIMG_BYTES;
+            ba.wimg = (const char*)fs->wstream + (size_t)b * (dtype == F16P ? B35S_WIMG_BYTES : B35_WIMG_BYTES);
             ba.zero = conv_zero_page();
-            hipError_t err = launch_block35(ba, dtype, s);
+            hipError_t err = dtype == F16P ? launch_block35s(ba, s) : launch_block35(ba, dtype, s);
             if (err != hipSuccess) return fail(VNF_E_HIP, std::string("fused Block35: ") + hipGetErrorString(err));
           }
           oi = fs->last - 1;
