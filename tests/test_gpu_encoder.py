@@ -166,7 +166,7 @@ def test_activation_contexts_let_calls_on_different_streams_overlap_without_chan
     assert sorted(got) == list(range(6)) and all(np.array_equal(got[i], want[i % 3]) for i in got)
 
 
-def test_irv1_split_f16_meets_the_1e4_gate_on_16bit_mfma(irv1_sd):
+def test_irv1_split_f16_meets_the_1e4_gate_on_16bit_mfma(irv1_sd, monkeypatch):
     """compute_dtype="f16x2": every weight / activation is an (hi, lo) pair of halves and each product is expanded on
     v_mfma_f32_16x16x32_f16 -- a 16-bit-operand MFMA path that must sit inside the north-star gate (<= 1e-4 L2 against the
     reference's own embeddings), with every stage tap within 1e-4 of the fp32 oracle (tolerance relative to the tap's
@@ -183,10 +183,19 @@ def test_irv1_split_f16_meets_the_1e4_gate_on_16bit_mfma(irv1_sd):
     taps = {}
     ref = irv1.irv1_forward(irv1_sd, x3, taps=taps).numpy()
     y3 = m(x3.cuda()).cpu().numpy()
+    # every stage tap on the per-convolution plan (VNF_FUSE=0: with the fused stem, conv2d_2a / 2b / maxpool_3a only
+    # ever exist in LDS); the taps the fused kernels do produce are checked on the default plan as well
+    monkeypatch.setenv("VNF_FUSE", "0")
+    plan = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype="f16x2", max_batch=8).eval()
+    assert np.linalg.norm(plan(x3.cuda()).cpu().numpy() - ref, axis=1).max() <= 1e-4
+    monkeypatch.delenv("VNF_FUSE")
+    for name in ["conv2d_1a", "conv2d_3b", "conv2d_4b", "repeat_1", "repeat_2", "block8"]:
+        got, want = m.tap(name, 3), taps[name].numpy()
+        assert np.abs(got - want).max() / max(1.0, np.abs(want).max()) <= 1e-4, ("fused plan", name)
     table = []
     for name in ["conv2d_1a", "conv2d_2a", "conv2d_2b", "maxpool_3a", "conv2d_3b", "conv2d_4a", "conv2d_4b",
                  "repeat_1", "mixed_6a", "repeat_2", "mixed_7a", "repeat_3", "block8"]:
-        got, want = m.tap(name, 3), taps[name].numpy()
+        got, want = plan.tap(name, 3), taps[name].numpy()
         assert got.shape == want.shape, name
         e = np.abs(got - want).max() / max(1.0, np.abs(want).max())
         table.append((name, e))
@@ -219,6 +228,8 @@ def test_persistent_block17_trunk_kernel_matches_the_unfused_plan_and_the_oracle
     x = seeded_normal((5, 3, 160, 160), 31)
     taps = {}
     ref = irv1.irv1_forward(irv1_sd, x, taps=taps).numpy()
+    if dt == "f16x2":
+        monkeypatch.setenv("VNF_FUSE", "1")   # the trunk kernel alone: the split-f16 stem / Block35 kernels are not bitwise the plan
     fused = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=5).eval()
     yf = fused(x.cuda()).cpu().numpy()
     tf = {n: fused.tap(n, 5) for n in ("mixed_6a", "repeat_2", "mixed_7a")}
@@ -356,3 +367,33 @@ def test_fused_block35_split_f16_matches_the_five_launch_plan_and_the_oracle(irv
     print("block35s repeat_1: vs unfused plan %.2e, vs oracle %.2e (unfused vs oracle %.2e)" % (e_plan, e_orc, np.abs(want_p - want_o).max() / scale))
     assert e_plan <= 2e-6 and e_orc <= 1e-5
     assert np.linalg.norm(yf - ref, axis=1).max() <= 1e-4 and np.linalg.norm(yf - yp, axis=1).max() <= 5e-6
+
+
+@pytest.mark.parametrize("n", [1, 3, 130])
+def test_fused_stem_split_f16_matches_the_plan_and_the_oracle(irv1_sd, monkeypatch, n):
+    """stem_mids.hip: conv2d_2a -> conv2d_2b -> maxpool_3a -> conv2d_3b as one rolling-row launch in the planar split-f16
+    dtype (vertical pooling maximum in registers, 2b's zero rows skipped).  Same products and the plan's (kh, kw, c)
+    order; the pooled values are split after the maximum exactly as the plan's pool does: conv2d_3b must agree with the
+    unfused plan to fp32 noise -- first / last rows and columns and the 128-image sub-batch boundary (n = 130) included
+    -- and with the oracle to the 1e-4 bar."""
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    from oracle import irv1
+    x = seeded_normal((n, 3, 160, 160), 191 + n)
+    monkeypatch.setenv("VNF_FUSE", "12")     # the stem kernel with conv2d_3b inside it
+    fused = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype="f16x2", max_batch=n).eval()
+    yf = fused(x.cuda()).cpu().numpy()
+    tf_ = fused.tap("conv2d_3b", n)
+    monkeypatch.setenv("VNF_FUSE", "0")
+    plain = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype="f16x2", max_batch=n).eval()
+    yp = plain(x.cuda()).cpu().numpy()
+    tp = plain.tap("conv2d_3b", n)
+    assert tf_.shape == tp.shape == (n, 80, 38, 38) and np.isfinite(tf_).all()
+    scale = np.abs(tp).max()
+    bad = np.argwhere(np.abs(tf_ - tp) > 2e-6 * scale)
+    assert len(bad) == 0, (len(bad), bad[:8], tf_[tuple(bad[0])], tp[tuple(bad[0])])
+    assert np.linalg.norm(yf - yp, axis=1).max() <= 5e-6
+    k = min(n, 3)
+    taps = {}
+    ref = irv1.irv1_forward(irv1_sd, x[:k], taps=taps).numpy()
+    assert np.abs(tf_[:k] - taps["conv2d_3b"].numpy()).max() / scale <= 1e-5
+    assert np.linalg.norm(yf[:k] - ref, axis=1).max() <= 1e-4

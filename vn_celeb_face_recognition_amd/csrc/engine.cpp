@@ -283,7 +283,6 @@ int Encoder::prepare_fused() {
   for (FusedStack& f : fused) {
     f.active = false;
     if (!enabled || (dtype != BF16 && dtype != F16 && dtype != F16P) || f.nblocks < 1 || f.nblocks > T17_MAX_BLOCKS) continue;
-    if (dtype == F16P && f.kind == 2) continue;   // planar split-f16: Block17 trunk and Block35 have fused twins (trunk17s / block35s.hip)
     if (f.kind == 2) {
       if (!(enabled & 4)) continue;
       const ConvLayer& c2a = convs[f.conv0];
@@ -293,24 +292,24 @@ int Encoder::prepare_fused() {
       StemMidPack pk;
       pk.w[0] = c2a.w; pk.kpad[0] = c2a.Kpad;
       pk.w[1] = c2b.w; pk.kpad[1] = c2b.Kpad;
-      f.wstream = dalloc(SM_WFRAG_BYTES);
+      bool ext_ok = false;
+      if ((enabled & 8) && f.ext_conv >= 0) {
+        const ConvLayer& c3b = convs[f.ext_conv];
+        ext_ok = c3b.cout == 80 && c3b.K == 64 && c3b.KH == 1 && c3b.ncls == 1 && c3b.nseg == 1 && c3b.res_buf < 0 && c3b.act == ACT_RELU &&
+                 bufs[f.ext_out_buf].C == 80;
+      }
+      if (dtype == F16P && !ext_ok) continue;   // the planar split-f16 stem kernel (stem_mids.hip) always carries conv2d_3b
+      f.wstream = dalloc(dtype == F16P ? SMS_WFRAG_BYTES : SM_WFRAG_BYTES);
       f.bias = (float*)dalloc(SM_BIAS * 4);
       if (!f.wstream || !f.bias) return VNF_E_HIP;
       VNF_HIP(hipMemcpy(f.bias, c2a.bias, 32 * 4, hipMemcpyDeviceToDevice));
       VNF_HIP(hipMemcpy(f.bias + 32, c2b.bias, 64 * 4, hipMemcpyDeviceToDevice));
-      VNF_HIP(stem_mid_repack(pk, f.wstream, 0));
+      VNF_HIP(dtype == F16P ? stem_mids_repack(pk, f.wstream, 0) : stem_mid_repack(pk, f.wstream, 0));
       VNF_HIP(hipDeviceSynchronize());
       f.macs_alg = c2a.macs_alg + c2b.macs_alg;
       f.active = true;
-      f.ext = false;
-      if ((enabled & 8) && f.ext_conv >= 0) {
-        const ConvLayer& c3b = convs[f.ext_conv];
-        if (c3b.cout == 80 && c3b.K == 64 && c3b.KH == 1 && c3b.ncls == 1 && c3b.nseg == 1 && c3b.res_buf < 0 && c3b.act == ACT_RELU &&
-            bufs[f.ext_out_buf].C == 80) {
-          f.ext = true;
-          f.macs_alg += c3b.macs_alg;
-        }
-      }
+      f.ext = ext_ok;
+      if (ext_ok) f.macs_alg += convs[f.ext_conv].macs_alg;
       continue;
     }
     if (f.kind == 35) {
@@ -757,7 +756,7 @@ int build_irv1(Encoder& e, WeightMap& wm) {
   // Infinity Cache; with conv2d_2a/2b/maxpool fused (one workgroup per image, no big intermediate) a sub-batch would
   // only leave half the CUs without a workgroup
   const int fuse_mask = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 15;
-  int chunk = ((fuse_mask & 4) && (e.dtype == BF16 || e.dtype == F16)) ? 256 : 128;
+  int chunk = ((fuse_mask & 4) && (e.dtype == BF16 || e.dtype == F16 || (e.dtype == F16P && (fuse_mask & 8)))) ? 256 : 128;
   if (const char* c = getenv("VNF_STEM_CHUNK")) chunk = atoi(c) > 0 ? atoi(c) : chunk;
   e.groups.push_back({0, stem_end, chunk});
   e.groups.push_back({stem_end, (int)e.ops.size(), 1 << 30});
@@ -1341,7 +1340,7 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
             sa.ldy = eb.C;
             sa.w3b = c3b.w; sa.b3b = c3b.bias; sa.k3b_pad = c3b.Kpad;
           }
-          hipError_t err = launch_stem_mid(sa, dtype, s);
+          hipError_t err = dtype == F16P ? launch_stem_mids(sa, s) : launch_stem_mid(sa, dtype, s);
           if (err != hipSuccess) return fail(VNF_E_HIP, std::string("fused stem: ") + hipGetErrorString(err));
           oi = (fs->ext ? fs->ext_last : fs->last) - 1;
           continue;

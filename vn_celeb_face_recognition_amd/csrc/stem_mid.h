@@ -26,6 +26,11 @@ struct StemMidPack {    // packed engine weights [rows][kpad], k = (kh, kw, c): 
   int kpad[2];
 };
 
+// planar split-f16 twin (stem_mids.hip): x / y are F16P tensors, weights F16P-packed; 108 fragments; conv2d_3b always fused
+constexpr int SMS_WFRAG_BYTES = 108 * 1024;
+hipError_t stem_mids_repack(const StemMidPack& p, void* out, hipStream_t s);
+hipError_t launch_stem_mids(const StemMidArgs& a, hipStream_t s);
+
 hipError_t stem_mid_repack(const StemMidPack& p, void* out, hipStream_t s);
 hipError_t launch_stem_mid(const StemMidArgs& a, int dtype, hipStream_t s);
 
