@@ -13,12 +13,16 @@ resulting (256,512) fp32 embeddings with one RCCL all-gather per step, overlappe
 step.  Rank 0 prints ONE JSON line.
 
 The default run (no --workload) carries, inside that one line:
-  * the headline leg (value / ms_per_step / roofline / cpu_baseline): bf16, BASELINE configs[1];
+  * the headline leg (value / ms_per_step / roofline / cpu_baseline): bf16, BASELINE configs[1]; "in_gate": the rate of
+    the f16x2 (split-f16) path that meets the 1e-4 gate, promoted from the legs;
   * "parity": measured L2 error of the timed dtype against the reference's own embeddings (tests/golden/
     irv1_seed0.npz) next to the 1e-4 north-star gate, and whether the timed 3-lane bs=256 output equals the same
     images embedded 8 at a time on one stream (bitwise) -- so the line says which path is inside the gate;
-  * "legs": the same workload timed in the other compute dtypes (f16x2 = split-f16, inside the gate; f16; f32);
-  * "pipeline": BASELINE's other half -- faces/sec end to end on synthetic 1080p frames (16 frames/step/GPU).
+  * "legs": the same workload timed in the other compute dtypes (f16x2 = split-f16, inside the gate; f16; f32), the
+    headline dtype on one lane, and BASELINE configs[4] (IR-100);
+  * "pipeline": BASELINE's other half -- faces/sec end to end on synthetic 1080p frames (16 frames/step/GPU, resident in
+    HBM); "pipeline_f16x2": the same with the in-gate encoder (the CLIs' default); "stream": that pipeline fed from
+    pinned host memory through the asynchronous uploader, with the measured H2D ceiling.
 """
 import argparse
 import json
@@ -174,25 +178,42 @@ def run_detect(args):
                      "kernel": "whole cascade priced on stage-1 (pyramid + P-Net) algorithmic bytes only: a lower bound"}}), flush=True)
 
 
-def pipeline_leg(args, rank, world, local, steps, warmup, lanes, want_cpu):
+def pipeline_leg(args, rank, world, local, steps, warmup, lanes, want_cpu, dtype=None, from_host=False):
     """BASELINE.json configs[2]/[3] -- faces/sec end to end (detect + align + embed + classify) on synthetic 1080p
-    frames, 16 frames per step per GPU, frames resident in HBM.  Returns the result dict on rank 0 (None elsewhere)."""
+    frames, 16 frames per step per GPU, 64 distinct frames.  from_host=False: frames resident in
+    HBM when the timed region starts (the contract's `value`); from_host=True: the frames start in PINNED HOST memory (a
+    decoder's staging ring) and every step uploads its 16 frames on the copy stream behind the GPU work of the steps
+    before it (upload.FrameUploader) -- the rate demo_video.py sees, bounded by PCIe.  Returns the result dict on rank
+    0 (None elsewhere)."""
     import torch
     import torch.distributed as dist
-    from vn_celeb_face_recognition_amd import dist as vdist, models
+    from vn_celeb_face_recognition_amd import models
     from vn_celeb_face_recognition_amd.pipeline import FacePipeline
     from vn_celeb_face_recognition_amd.synth import make_frames
+    from vn_celeb_face_recognition_amd.upload import FrameUploader
     dev = torch.device("cuda", local)
-    NF, PER = 16, 8
-    frames, truth = make_frames(NF * 2, PER, seed=rank)
+    dtype = dtype or args.dtype
+    NF, PER, NB = 16, 8, 4
+    frames, truth = make_frames(NF * NB, PER, seed=rank)
     # two detector handles: each gets a host thread and a HIP stream, so one batch's detection runs under the
     # other's host synchronisations (FacePipeline.submit)
     det = [make_detector(args, models, dev, NF, PER) for _ in range(args.detectors)]
-    enc = models.InceptionResnetV1(pretrained=None, compute_dtype=args.dtype, max_batch=max(256, args.embed_batch)).to(dev).eval()
+    enc = models.InceptionResnetV1(pretrained=None, compute_dtype=dtype, max_batch=max(256, args.embed_batch)).to(dev).eval()
     clf = models.MLPModel(512, 1001).to(dev).eval()
     pipe = FacePipeline(det, enc, clf, {"label": list(range(1001)), "name": ["c%d" % i for i in range(1001)]}, 160, 0.0,
                         embed_batch=args.embed_batch, embed_lanes=lanes)
-    batches = [torch.from_numpy(frames[i * NF:(i + 1) * NF]).to(dev) for i in range(2)]
+    if from_host:
+        host = [torch.from_numpy(frames[i * NF:(i + 1) * NF]).pin_memory() for i in range(NB)]
+        up = FrameUploader(dev, depth=4)
+        batches = None
+    else:
+        batches = [torch.from_numpy(frames[i * NF:(i + 1) * NF]).to(dev) for i in range(NB)]
+    # fixed-size exchange of the ranks' embeddings (weak scaling: every rank embeds its own frames; the per-batch face
+    # count is data dependent, so the block carries a count row like video.run_stream's exchange -- no host read inside)
+    CAP = 256
+    gathered = [torch.empty((world * (CAP + 1), 512), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    blocks = [torch.zeros((CAP + 1, 512), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    state = {"n": 0}
 
     inflight = []
 
@@ -200,13 +221,22 @@ def pipeline_leg(args, rank, world, local, steps, warmup, lanes, want_cpu):
         # in submission order: the collective sequence is identical on every rank
         n = t.n_faces
         if world > 1:
-            vdist.all_gather_embeddings(t.result()[2])     # result() orders this stream after the batch's lane
+            emb = t.result()[2]                             # result() orders this stream after the batch's lane
+            k = state["n"] & 1
+            state["n"] += 1
+            blocks[k][0, 0] = float(n)
+            blocks[k][1:1 + min(n, CAP)] = emb[:CAP]
+            dist.all_gather_into_tensor(gathered[k], blocks[k])
         return n
 
     def step(i):
         # throughput mode: batches are in flight together (detection streams + embedding stream); every batch is
         # retired inside the timed region and the closing torch.cuda.synchronize() waits for all device work
-        inflight.append(pipe.submit(batches[i & 1], classify=True))
+        if from_host:
+            fr, ready = up.upload(host[i % NB])
+            inflight.append(pipe.submit(fr, classify=True, ready=ready))
+        else:
+            inflight.append(pipe.submit(batches[i % NB], classify=True))
         return retire(inflight.pop(0)) if len(inflight) > 2 * args.detectors else 0
 
     def drain():
@@ -236,21 +266,42 @@ def pipeline_leg(args, rank, world, local, steps, warmup, lanes, want_cpu):
     if world > 1:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); wall = float(mx[0])
         dist.all_reduce(tot); faces = int(tot[1].item())
-    stage_ms = det[0].stage_times(batches[0]) if rank == 0 and hasattr(det[0], "stage_times") else None
+    h2d = None
+    if from_host and rank == 0:
+        # the PCIe ceiling of this leg: the same 16-frame batches, upload only
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(8):
+            up.upload(host[i % NB])
+        up.stream.synchronize()
+        dt = time.perf_counter() - t1
+        h2d = {"frames_per_s": round(8 * NF / dt, 1), "GBps": round(8 * host[0].numel() / dt / 1e9, 2)}
+    stage_ms = None
+    if rank == 0 and hasattr(det[0], "stage_times") and not from_host:
+        stage_ms = det[0].stage_times(batches[0])
     out = None
     if rank == 0:
         out = {"metric": "faces/sec end-to-end (detect+embed+classify) on 1080p frames", "value": round(faces / wall, 1),
                "unit": "faces/s", "n_gpus": world, "steps": steps, "warmup": warmup,
                "ms_per_step": round(wall * 1e3 / steps, 4), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[2]+[3]: " + ("MTCNN" if args.detector == "mtcnn" else "RetinaFace (synthetic weights)") +
                                       " detect + align + IRv1 embed + MLP classify, "
-                                      "synthetic 1080p frames, %d frames/step/GPU, %d pasted faces/frame; detection and embedding on "
-                                      "separate streams, faces embedded in groups of >= %d" % (NF, PER, args.embed_batch),
-                          "frames_per_s": round(world * NF * steps / wall, 1), "min_face_size": 50},
-               "roofline": pipeline_roofline(stage_ms, NF)}
+                                      "synthetic 1080p frames (%d distinct), %d frames/step/GPU, %d pasted faces/frame; detection and embedding on "
+                                      "separate streams, faces embedded in groups of >= %d; %s" % (
+                                          NF * NB, NF, PER, args.embed_batch,
+                                          "frames start in pinned host memory, one asynchronous upload per step" if from_host
+                                          else "frames resident in HBM"),
+                          "frames_per_s": round(world * NF * steps / wall, 1), "min_face_size": 50,
+                          "detector_handles": args.detectors, "encoder_dtype": dtype}}
+        if from_host:
+            out["h2d_ceiling"] = h2d
+        else:
+            out["roofline"] = pipeline_roofline(stage_ms, NF)
         if want_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline_pipeline(frames)
+    if from_host:
+        up.close()
     del pipe, det, enc, clf
     torch.cuda.empty_cache()
     return out
@@ -275,14 +326,29 @@ def pipeline_roofline(stages, nf):
             "per_kernel": per, "stage_ms": {k: round(v["ms"], 4) for k, v in stages.items()}}
 
 
-ROUND = "r02"   # profiles/<ROUND>_traffic.json is quoted in roofline.traffic
+ROUND = "r03"   # profiles/<ROUND>_traffic.json is quoted in roofline.traffic
 # float64 sum of |embedding| over the bs=256 seed-0 bf16 input of the headline leg; tests/test_gpu_bench_config.py
 # asserts the same value on the same configuration (deterministic kernels: any change of the arithmetic shows here)
 CHECKSUMS = {("irv1", "bf16"): 4542.960144015937, ("irv1", "f16"): 4543.280890313676,
              ("irv1", "f16x2"): 4543.173085557737, ("irv1", "f32"): 4543.173369363214}
 
 
-def embed_leg(args, dtype, rank, world, dev, n_lanes, steps, warmup, want_cpu, with_parity=True):
+class LegError(Exception):
+    """a leg failed on SOME rank: raised on every rank after the ranks agreed (so nobody is left inside a collective)"""
+
+
+def agree(failed, world, dev):
+    """True on every rank if `failed` is true on any rank (one all_reduce; identity for a single process)."""
+    if world <= 1:
+        return bool(failed)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1.0 if failed else 0.0], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item() > 0)
+
+
+def embed_leg(args, dtype, rank, world, dev, n_lanes, steps, warmup, want_cpu, with_parity=True, model_name=None):
     """Time the embed path in one compute dtype: `warmup` untimed + exactly `steps` timed steps bracketed by barrier +
     synchronize; consecutive (independent) batches rotate over `n_lanes` streams / activation contexts.  Returns the
     result dict (rank 0) or None."""
@@ -296,12 +362,21 @@ def embed_leg(args, dtype, rank, world, dev, n_lanes, steps, warmup, want_cpu, w
     # input tensor dtype: the 16-bit storage paths take 16-bit crops (BASELINE configs[1]: "synthetic 160x160 bf16"),
     # the fp32-class paths (f32, f16x2) take fp32 crops
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f16x2": torch.float32}[dtype]
-    if args.model == "irv1":
-        model = InceptionResnetV1(pretrained=None, device=dev, compute_dtype=dtype, max_batch=BATCH).eval()
-        size, macs, mname = 160, IRV1_MACS_PER_IMAGE, "InceptionResnetV1"
-    else:
-        model = iresnet100(pretrained=False, compute_dtype=dtype, max_batch=BATCH).to(dev).eval()
-        size, macs, mname = 112, IR100_MACS_PER_IMAGE, "IResNet-100"
+    model_name = model_name or args.model
+    model, err = None, None
+    try:     # creation is the part that can fail on one rank only (memory, a missing kernel): agree before any collective
+        if model_name == "irv1":
+            model = InceptionResnetV1(pretrained=None, device=dev, compute_dtype=dtype, max_batch=BATCH).eval()
+            size, macs, mname = 160, IRV1_MACS_PER_IMAGE, "InceptionResnetV1"
+        else:
+            model = iresnet100(pretrained=False, compute_dtype=dtype, max_batch=BATCH).to(dev).eval()
+            size, macs, mname = 112, IR100_MACS_PER_IMAGE, "IResNet-100"
+        model(torch.zeros((2, 3, size, size), dtype=tdt, device=dev))
+        torch.cuda.synchronize()
+    except Exception as e:
+        err = "%s: %s" % (type(e).__name__, e)
+    if agree(err is not None, world, dev):
+        raise LegError(err or "another rank failed to create the %s / %s encoder" % (model_name, dtype))
     g = torch.Generator().manual_seed(rank)
     x = torch.randn((BATCH, 3, size, size), generator=g).to(dev).to(tdt)
     gathered = [torch.empty((world * BATCH, 512), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
@@ -358,9 +433,11 @@ def embed_leg(args, dtype, rank, world, dev, n_lanes, steps, warmup, want_cpu, w
         wall = float(t.item())
     emb_timed = emb.clone()
     checksum = float(emb_timed.double().abs().sum().item())
-    want = CHECKSUMS.get((args.model, dtype))
-    if not (checksum == checksum) or (want is not None and rank == 0 and abs(checksum - want) > 1e-9 * want):
-        raise SystemExit("embedding checksum %.12f of the timed configuration differs from the pinned %r" % (checksum, want))
+    want = CHECKSUMS.get((model_name, dtype))
+    bad = not (checksum == checksum) or (want is not None and rank == 0 and abs(checksum - want) > 1e-9 * want)
+    if agree(bad, world, dev):      # every rank leaves together: nobody waits in the next barrier for a rank that exited
+        raise LegError("embedding checksum %.12f of the timed configuration (rank %d) differs from the pinned %r, or is not finite "
+                       "on some rank" % (checksum, rank, want))
 
     out = None
     if rank == 0:
@@ -372,7 +449,7 @@ def embed_leg(args, dtype, rank, world, dev, n_lanes, steps, warmup, want_cpu, w
             same = bool(torch.equal(serial, emb_timed))
             parity = {"timed_output_bitwise_equals_serial_8_at_a_time": same, "checksum_abs_sum": checksum}
             # (b) this dtype against the reference's own embeddings (golden inputs: 4 seeded + 2 real crops)
-            if args.model == "irv1":
+            if model_name == "irv1":
                 gd = np.load(os.path.join(REPO, "tests", "golden", "irv1_seed0.npz"))
                 xg = torch.randn((6, 3, 160, 160), generator=torch.Generator().manual_seed(int(gd["input_seed"])))
                 xg[4:6] = torch.from_numpy(gd["real_inputs"].astype(np.float32))
@@ -388,7 +465,7 @@ def embed_leg(args, dtype, rank, world, dev, n_lanes, steps, warmup, want_cpu, w
         alg, executed = model.flops_per_image()
         traffic = None   # HBM bytes per step from rocprofv3 PMC passes (collected separately, profiles/)
         tpath = os.path.join(REPO, "profiles", "%s_traffic.json" % ROUND)
-        if dtype == "bf16" and args.model == "irv1" and os.path.exists(tpath):
+        if dtype == "bf16" and model_name == "irv1" and os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_step")
         out = {
@@ -397,7 +474,7 @@ def embed_leg(args, dtype, rank, world, dev, n_lanes, steps, warmup, want_cpu, w
             "warmup": warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: %s embedding only, synthetic %dx%d %s, "
-                                   "bs=256 per GPU, generator weights seed 0" % (1 if args.model == "irv1" else 4, mname, size, size, dtype),
+                                   "bs=256 per GPU, generator weights seed 0" % (1 if model_name == "irv1" else 4, mname, size, size, dtype),
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "parallelism": "dp%d (frames sharded, all-gather of embeddings)" % world,
                        "lanes": len(lanes)},
@@ -409,14 +486,14 @@ def embed_leg(args, dtype, rank, world, dev, n_lanes, steps, warmup, want_cpu, w
                          "kernel": "every kernel of one embed step (fused inception-block kernels + implicit-GEMM convolutions; tile "
                                    "configuration per layer chosen by the create-time autotuner); device time by HIP events; "
                                    "achieved = algorithmic FLOP (2 x 1 417 662 304 MAC x 256) / device time per step; the 16-bit MFMA "
-                                   "peak is the yardstick for bf16, f16 and f16x2 (f16x2 issues 4 MFMAs per algorithmic one)",
+                                   "peak is the yardstick for bf16, f16 and f16x2 (f16x2 issues 3 MFMAs per algorithmic one: hi.hi + hi.lo + lo.hi)",
                          "flop_per_step_algorithmic": flop_per_step,
                          "flop_per_image_executed": executed, "flop_per_image_counted_by_engine": alg,
                          "device_ms_per_step": round(dev_ms / steps, 4)},
         }
         if parity is not None:
             out["parity"] = parity
-        if want_cpu and world == 1 and args.model == "irv1":
+        if want_cpu and world == 1 and model_name == "irv1":
             out["cpu_baseline"] = cpu_baseline()
     del model
     torch.cuda.empty_cache()
@@ -425,9 +502,9 @@ def embed_leg(args, dtype, rank, world, dev, n_lanes, steps, warmup, want_cpu, w
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="all", choices=["all", "embed", "pipeline", "detect"],
-                    help="all (default): the embed headline leg + the other dtype legs + the pipeline leg in ONE JSON line; "
-                         "embed / pipeline / detect: that leg alone")
+    ap.add_argument("--workload", default="all", choices=["all", "embed", "pipeline", "stream", "detect"],
+                    help="all (default): the embed headline leg + the other legs + the pipeline legs in ONE JSON line; "
+                         "embed / pipeline / stream (pipeline from pinned host memory) / detect: that leg alone")
     ap.add_argument("--embed-batch", type=int, default=256,
                     help="pipeline workload: faces of consecutive frame batches are embedded together once this many wait "
                          "(0: every frame batch on its own)")
@@ -467,12 +544,12 @@ def main():
     p = None
     pipe_first = os.environ.get("BENCH_PIPE_FIRST", "0") != "0"
 
-    def run_pipeline():
-        st = args.steps if args.workload == "pipeline" else max(10, args.steps // 2)
+    def run_pipeline(dtype=None, from_host=False, cpu=True):
+        st = args.steps if args.workload in ("pipeline", "stream") else max(10, args.steps // 2)
         try:
-            return pipeline_leg(args, rank, world, local, st, args.warmup, pipe_lanes, want_cpu)
+            return pipeline_leg(args, rank, world, local, st, args.warmup, pipe_lanes, want_cpu and cpu, dtype=dtype, from_host=from_host)
         except Exception as e:
-            if args.workload == "pipeline":
+            if args.workload in ("pipeline", "stream"):
                 raise
             return {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -483,25 +560,44 @@ def main():
     if args.workload in ("all", "embed"):
         out = embed_leg(args, args.dtype, rank, world, dev, emb_lanes, args.steps, args.warmup, want_cpu)
     if args.workload == "all" and args.model == "irv1":
-        # the other compute dtypes: shorter legs (the f32 leg runs ~7 ms steps), one rank each, no CPU baseline
+        # the other compute dtypes: shorter legs (the f32 leg runs ~7 ms steps), no CPU baseline; then the headline dtype
+        # on ONE lane (no overlap of independent batches) and BASELINE configs[4] (IR-100 swap-in encoder)
         legs = {}
-        for dt in [d for d in args.legs.split(",") if d and d != args.dtype]:
-            st = max(5, args.steps // (5 if dt == "f32" else 2))
+        keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "parity")
+        plan = [(dt, dt, emb_lanes, "irv1") for dt in args.legs.split(",") if dt and dt != args.dtype]
+        plan += [("%s_lanes1" % args.dtype, args.dtype, 1, "irv1"), ("ir100_%s" % args.dtype, args.dtype, emb_lanes, "ir100")]
+        for name, dt, ln, mdl in plan:
+            st = max(5, args.steps // (5 if (dt == "f32" or mdl == "ir100") else 2))
             try:
-                r = embed_leg(args, dt, rank, world, dev, emb_lanes, st, max(3, args.warmup // 2), False)
-            except Exception as e:    # a failing side leg must not take the headline line with it
+                r = embed_leg(args, dt, rank, world, dev, ln, st, max(3, args.warmup // 2), False, with_parity=(mdl == "irv1" and ln > 1),
+                              model_name=mdl)
+            except Exception as e:    # a failing side leg must not take the headline line with it (the ranks agreed: LegError)
                 r = {"error": "%s: %s" % (type(e).__name__, e)}
             if rank == 0:
-                legs[dt] = r if "error" in r else {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "parity") if k in r}
+                legs[name] = r if "error" in r else {k: r[k] for k in keep if k in r}
         if rank == 0:
             out["legs"] = legs
+            # the headline dtype is BASELINE's (bf16, outside the 1e-4 gate); the in-gate path's rate next to it
+            ig = legs.get("f16x2")
+            if ig and "error" not in ig:
+                out["in_gate"] = {"dtype": "f16x2", "value": ig["value"], "unit": ig["unit"],
+                                  "within_gate": bool(ig.get("parity", {}).get("within_gate")), "frac": ig["roofline"]["frac"]}
     if args.workload in ("all", "pipeline") and not pipe_first:
         p = run_pipeline()
-    if rank == 0 and args.workload in ("all", "pipeline"):
-        if args.workload == "pipeline":
+    if args.workload == "stream":
+        p = run_pipeline(dtype=args.dtype, from_host=True)
+    if rank == 0 and args.workload in ("all", "pipeline", "stream"):
+        if args.workload in ("pipeline", "stream"):
             out = p
         else:
             out["pipeline"] = p
+    if args.workload == "all":
+        # the same pipeline with the in-gate encoder (what the CLIs run by default), then from pinned host memory
+        q = run_pipeline(dtype="f16x2", cpu=False)
+        r = run_pipeline(dtype="f16x2", from_host=True, cpu=False)
+        if rank == 0:
+            out["pipeline_f16x2"] = q
+            out["stream"] = r
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -3,10 +3,13 @@
 
     layer_trace.py <plan.txt (stdout of pmc_one_step.py with VNF_PRINT_PLAN=1)> <kernel_trace.csv> <steps> <lanes> > table
 
-Dispatches of one stream follow the plan order, so the i-th vnf dispatch of a step on a stream is plan launch i; rows
-report the average device time of that launch over the traced steps, its algorithmic GFLOP and the achieved TFLOP/s --
-measured while the other lanes' kernels share the GPU (that is the benchmarked mode), so the per-row times sum to more
-than the step time."""
+Dispatches of one stream follow the plan order.  A step ends with its l2norm dispatch, so every stream's dispatch list is
+cut into steps at the l2norm kernels; only steps with exactly the plan's number of launches count (tuning launches at
+create time form irregular groups and drop out), and EVERY dispatch must be of the kernel family its plan row names
+(stem_conv1a / stem_mid / block35 / block17_trunk / maxpool / avgpool / l2norm / a conv_* kernel) -- a mismatch aborts:
+a shifted table is worse than none.  Rows report the average device time of that launch over the traced steps, its
+algorithmic GFLOP and the achieved TFLOP/s -- measured while the other lanes' kernels share the GPU (the benchmarked
+mode), so the per-row times sum to more than the step time."""
 import csv, sys
 from collections import defaultdict
 
@@ -23,6 +26,28 @@ for line in open(sys.argv[1]):
             grp = [(l + " [sub-batch %d/%d]" % (r + 1, rep), g / rep) for r in range(rep) for (l, g) in plan]
             plan = grp
 steps, lanes = int(sys.argv[3]), int(sys.argv[4])
+
+
+def family(label):
+    if label.startswith("conv2d_1a (direct"):
+        return ("stem_conv1a",)
+    if label.startswith("conv2d_2a+"):
+        return ("stem_mid",)
+    if label.startswith("repeat_1 (fused"):
+        return ("block35",)
+    if label.startswith("repeat_2 (persistent"):
+        return ("block17_trunk",)
+    if label.startswith("maxpool"):
+        return ("maxpool3s2",)
+    if label.startswith("avgpool"):
+        return ("avgpool",)
+    if label.startswith("l2norm"):
+        return ("l2norm",)
+    if label.startswith("pack"):
+        return ("pack_input",)
+    return ("conv_igemm", "conv_patch")     # conv_igemm_dma / conv_igemm_ws / conv_igemm (fallback) / conv_patch
+
+
 rows = [r for r in csv.DictReader(open(sys.argv[2])) if "vnf" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 by_stream = defaultdict(list)
@@ -33,17 +58,27 @@ acc = defaultdict(list)
 names = {}
 used = 0
 for sid, rs in by_stream.items():
-    if len(rs) < per:
-        continue
-    tail = rs[-(len(rs) // per) * per:] if len(rs) % per else rs     # warm-up dispatches (tuning) come first
-    # keep only the last `steps`-worth of whole steps of this stream
-    nst = min(len(tail) // per, (steps + lanes - 1) // lanes)
-    tail = tail[-nst * per:]
-    for i, r in enumerate(tail):
-        acc[i % per].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-        names[i % per] = r["Kernel_Name"].split("(")[0][:60]
-    used += nst
-print("# per-launch device time by plan position, %d steps over %d streams (3-lane mode: kernels of other lanes share the GPU)" % (used, len(by_stream)))
+    groups, cur = [], []
+    for r in rs:
+        cur.append(r)
+        if "l2norm_kernel" in r["Kernel_Name"]:
+            groups.append(cur)
+            cur = []
+    good = [g for g in groups if len(g) == per]
+    good = good[-((steps + lanes - 1) // lanes):]          # the last whole steps of this stream: the traced ones
+    for g in good:
+        for i, r in enumerate(g):
+            kn = r["Kernel_Name"]
+            if not any(f in kn for f in family(plan[i][0])):
+                sys.exit("layer_trace: dispatch %d of a step on stream %s is %s, the plan row is %r -- refusing to print a shifted table"
+                         % (i, sid, kn[:80], plan[i][0]))
+            acc[i].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            names[i] = kn.split("(")[0].replace("void vnf::", "").replace("vnf::", "")[:64]
+    used += len(good)
+if used == 0:
+    sys.exit("layer_trace: no stream holds a whole step of %d launches" % per)
+print("# per-launch device time by plan position, %d steps over %d streams (%d-lane mode: kernels of other lanes share the GPU);" % (used, len(by_stream), lanes))
+print("# every dispatch checked against its plan row's kernel family")
 print("%-34s %10s %10s %10s  %s" % ("layer", "avg us", "GFLOP", "TFLOP/s", "kernel"))
 tot_us = tot_gf = 0.0
 for i in range(per):
