@@ -204,7 +204,7 @@ def pipeline_leg(args, rank, world, local, steps, warmup, lanes, want_cpu, dtype
                         embed_batch=args.embed_batch, embed_lanes=lanes)
     if from_host:
         host = [torch.from_numpy(frames[i * NF:(i + 1) * NF]).pin_memory() for i in range(NB)]
-        up = FrameUploader(dev, depth=4)
+        up = FrameUploader(dev, depth=2 * args.detectors + 4)
         batches = None
     else:
         batches = [torch.from_numpy(frames[i * NF:(i + 1) * NF]).to(dev) for i in range(NB)]
@@ -220,6 +220,10 @@ def pipeline_leg(args, rank, world, local, steps, warmup, lanes, want_cpu, dtype
     def retire(t):
         # in submission order: the collective sequence is identical on every rank
         n = t.n_faces
+        if from_host:
+            if t.event is None and n:
+                t.result()                                  # its faces were still waiting for a full embed batch
+            up.release(t.upload_slot, t.event)              # the frames' last reader (the warp) precedes this event
         if world > 1:
             emb = t.result()[2]                             # result() orders this stream after the batch's lane
             k = state["n"] & 1
@@ -233,8 +237,15 @@ def pipeline_leg(args, rank, world, local, steps, warmup, lanes, want_cpu, dtype
         # throughput mode: batches are in flight together (detection streams + embedding stream); every batch is
         # retired inside the timed region and the closing torch.cuda.synchronize() waits for all device work
         if from_host:
-            fr, ready = up.upload(host[i % NB])
-            inflight.append(pipe.submit(fr, classify=True, ready=ready))
+            # the upload runs one batch AHEAD of the submit (submit blocks on the detector's read-back): every timed
+            # step issues exactly one upload and consumes the one issued in the step before
+            if state.get("up") is None:
+                state["up"] = up.upload(host[i % NB]) + (up.last_slot,)
+            fr, ready, slot = state["up"]
+            state["up"] = up.upload(host[(i + 1) % NB]) + (up.last_slot,)
+            t = pipe.submit(fr, classify=True, ready=ready)
+            t.upload_slot = slot
+            inflight.append(t)
         else:
             inflight.append(pipe.submit(batches[i % NB], classify=True))
         return retire(inflight.pop(0)) if len(inflight) > 2 * args.detectors else 0

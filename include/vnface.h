@@ -157,9 +157,12 @@ typedef struct {
 int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const vnf_tensor_desc* rnet, int n_rnet,
                      const vnf_tensor_desc* onet, int n_onet, const vnf_mtcnn_cfg* cfg, vnf_handle* out);
 /* frames: device (B,H,W,3) uint8 RGB.  Results stay on the device for vnf_align and are also
- * copied to the caller's host arrays.  The call synchronises the stream up to three times: after stage 1
- * and after stage 2 to size the next stage's launches from the candidate counts (the stage boundaries of
- * detect_face.py:25-185), and at the end for the results:
+ * copied to the caller's host arrays.  The reference synchronises at both stage boundaries to shape its tensors
+ * (detect_face.py:96-146); this call synchronises the stream ONCE, at the end, for the results: stages 2 and 3 are
+ * launched with the previous call's candidate counts (plus head room) as launch bounds, every kernel reads the true
+ * counts from device memory, and the final read-back tells whether the bounds covered them.  If not -- or on the first
+ * call of a frame size -- stage 1's counts are read and stages 2 / 3 run with exact bounds (one more synchronisation);
+ * the results are identical either way (VNF_MTCNN_SPEC=0 always takes the second path):
  *   counts[B]            faces per frame
  *   boxes[max_out*4]     x1,y1,x2,y2 fp32, frames concatenated in order
  *   probs[max_out]

@@ -317,3 +317,40 @@ def test_stage1_table_capacity_is_an_error_not_a_truncation():
     if len(ob):
         assert np.abs(np.asarray(bb) - np.asarray(ob)).max() <= 1e-3
         assert np.abs(np.asarray(pp) - np.asarray(op_)).max() <= 1e-5
+
+
+def test_speculative_stage_sizing_is_exact_on_hits_and_misses(monkeypatch):
+    """vnf_mtcnn_detect sizes stages 2 / 3 from the previous call's candidate counts and synchronises once
+    (detect_face.py:96-146 synchronises at both stage boundaries).  Hit (same frames again), miss (a far busier batch
+    after a blank one: the bounds are too small, stages 2 / 3 re-run with exact bounds) and the always-exact path
+    (VNF_MTCNN_SPEC=0) must return identical detections, equal to the oracle's."""
+    from vn_celeb_face_recognition_amd.models import MTCNN
+    from vn_celeb_face_recognition_amd.synth import make_frames
+    busy, _ = make_frames(2, 8, seed=11)
+    sparse, _ = make_frames(2, 1, seed=12)
+    blank = np.full_like(busy, 90)
+
+    def run(det, fr):
+        b, p, l = det.inference(list(fr), landmark=True)
+        return [np.asarray(x).reshape(-1, 4) for x in b], [np.asarray(x).reshape(-1) for x in p], [np.asarray(x).reshape(-1, 10) for x in l]
+
+    def same(a, b):
+        return all(np.array_equal(x, y) for u, v in zip(a, b) for x, y in zip(u, v))
+
+    det = MTCNN(keep_all=True, min_face_size=50, device="cuda:0", max_batch=2)
+    first = run(det, busy)                 # first call of this frame size: exact path
+    assert sum(len(x) for x in first[0]) >= 12
+    assert same(run(det, busy), first)     # hit
+    assert same(run(det, busy), first)
+    assert all(len(x) == 0 for x in run(det, blank)[0])   # no candidates at all: the bounds shrink to their floor
+    assert same(run(det, busy), first)     # miss: far more candidates than the previous call's bounds
+    sp = run(det, sparse)                  # over-provisioned bounds: the nets also run on unused tail rows
+    assert same(run(det, busy), first) and same(run(det, sparse), sp)
+    monkeypatch.setenv("VNF_MTCNN_SPEC", "0")
+    exact = MTCNN(keep_all=True, min_face_size=50, device="cuda:0", max_batch=2)
+    assert same(run(exact, busy), first) and same(run(exact, sparse), sp) and same(run(exact, busy), first)
+    p, r, o = mtcnn_state_dicts()
+    ob, _, ol = om.mtcnn_detect(list(busy), p, r, o, min_face_size=50, ties="table")
+    for i in range(2):
+        assert len(ob[i]) == len(first[0][i])
+        assert np.abs(first[0][i] - np.asarray(ob[i]).reshape(-1, 4)).max() <= 1e-3

@@ -1457,6 +1457,8 @@ struct Mtcnn : HandleBase {
   int* h_pin = nullptr;
   int fin_fast = FIN_FAST;
   int last_b = 0;  // frames of the last vnf_mtcnn_detect (vnf_mtcnn_results_device)
+  struct Spec { bool valid = false; int b = 0, H = 0, W = 0, max2 = 0, total2 = 0, max3 = 0, total3 = 0; } spec;   // launch sizes of stages 2 / 3 from the previous call
+  long long spec_misses = 0;
   ~Mtcnn() override { delete renc; delete oenc; if (h_pin) (void)hipHostFree(h_pin); }
   size_t cap_px = 0, cap_p1 = 0, cap_c2 = 0, cap_out = 0;
   std::vector<float> h_fin;
@@ -1826,13 +1828,10 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
       return fail(VNF_E_CAPACITY, "mtcnn: candidate table overflow (status " + std::to_string(st) + ")");
     return VNF_OK;
   };
-  int r = read_counts();
-  if (r != VNF_OK) return r;
-  mark("host_sync_1", 0);
-  int max2 = 0;
-  for (int i = 0; i < B; ++i) max2 = std::max(max2, h[i]);
-  if (max2 == 0) return VNF_OK;
-  // ---- stage 2
+  // ---- stages 2 and 3 as launch sequences sized by (largest per-frame candidate count, total candidates): every kernel
+  // reads the true counts from device memory and leaves early past them, so any UPPER bound gives the exact result (the
+  // nets then also run on the unused tail rows of the dense batch); an under-estimate leaves candidates out and is
+  // detected after the read-back.
   const bool crop_fast = (W * 3) % 16 == 0 && ((reinterpret_cast<uintptr_t>(frames)) & 15) == 0;
   auto crop = [&](const Row* rws, const int* cntp, int maxc, int S, float* dst, const int* offs, int c0, int cap) {
     if (crop_fast)
@@ -1873,49 +1872,97 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
     }
     return VNF_OK;
   };
-  int total2 = 0;
-  for (int i = 0; i < B; ++i) total2 += h[i];
-  if (m->renc) {
-    r = run_net(m->renc, m->r_cap, m->rows, m->row_cnt, max2, total2, 24, 8, m->rout, 5);
-    if (r != VNF_OK) return r;
-  } else {
-    crop(m->rows, m->row_cnt, max2, 24, m->crops, nullptr, 0, 0);
-    hipLaunchKernelGGL(rnet_kernel, dim3(max2, B), dim3(256), (13552 + 3388 + 864) * 4, s, m->crops, m->row_cnt, m->rw, m->rout);
-  }
   const size_t lds_post = (size_t)KEEP * 28 + 256 * 20 + KEEP * 16;
-  hipLaunchKernelGGL(stage2_post_kernel, dim3(B), dim3(256), lds_post, s, m->rows, m->row_cnt, m->rout, cfg.thresholds[1], 0.7f,
-                     W, H, m->rows3, m->row3_cnt, m->status);
-  VNF_HIP(hipGetLastError());
-  mark("stage2_post", 0);
-  r = read_counts();
-  if (r != VNF_OK) return r;
-  mark("host_sync_2", 0);
-  int max3 = 0;
-  for (int i = 0; i < B; ++i) max3 = std::max(max3, h[cfg.max_batch + i]);
-  if (max3 == 0) return VNF_OK;
-  // ---- stage 3
-  int total3 = 0;
-  for (int i = 0; i < B; ++i) total3 += h[cfg.max_batch + i];
-  if (m->oenc) {
-    r = run_net(m->oenc, m->o_cap, m->rows3, m->row3_cnt, max3, total3, 48, 16, m->oout, 15);
-    if (r != VNF_OK) return r;
-  } else {
-    crop(m->rows3, m->row3_cnt, max3, 48, m->crops, nullptr, 0, 0);
-    hipLaunchKernelGGL(onet_kernel, dim3(max3, B), dim3(512), (16928 + 14112 + 6912 + 1152) * 4, s, m->crops, m->row3_cnt, m->ow, m->oout);
-  }
-  hipLaunchKernelGGL(stage3_post_kernel, dim3(B), dim3(256), lds_post, s, m->rows3, m->row3_cnt, m->oout, cfg.thresholds[2], 0.7f,
-                     cfg.select_largest, m->fin, m->fin_cnt, m->status);
-  m->last_b = B;
-  hipLaunchKernelGGL(pack_results_kernel, dim3(B), dim3(256), 0, s, m->row_cnt, ncnt, m->fin, m->fin_cnt, B, m->stage);
-  VNF_HIP(hipGetLastError());
-  mark("stage3_post", 0);
-  VNF_HIP(hipMemcpyAsync(h, m->stage, ((size_t)ncnt + (size_t)B * FIN_FAST * 15) * 4, hipMemcpyDeviceToHost, s));
-  VNF_HIP(hipStreamSynchronize(s));
-  mark("readback", 0);
-  {
+  auto stage2 = [&](int max2, int total2) -> int {
+    if (m->renc) {
+      const int rc = run_net(m->renc, m->r_cap, m->rows, m->row_cnt, max2, total2, 24, 8, m->rout, 5);
+      if (rc != VNF_OK) return rc;
+    } else {
+      crop(m->rows, m->row_cnt, max2, 24, m->crops, nullptr, 0, 0);
+      hipLaunchKernelGGL(rnet_kernel, dim3(max2, B), dim3(256), (13552 + 3388 + 864) * 4, s, m->crops, m->row_cnt, m->rw, m->rout);
+    }
+    hipLaunchKernelGGL(stage2_post_kernel, dim3(B), dim3(256), lds_post, s, m->rows, m->row_cnt, m->rout, cfg.thresholds[1], 0.7f,
+                       W, H, m->rows3, m->row3_cnt, m->status);
+    VNF_HIP(hipGetLastError());
+    mark("stage2_post", 0);
+    return VNF_OK;
+  };
+  auto stage3 = [&](int max3, int total3) -> int {
+    if (m->oenc) {
+      const int rc = run_net(m->oenc, m->o_cap, m->rows3, m->row3_cnt, max3, total3, 48, 16, m->oout, 15);
+      if (rc != VNF_OK) return rc;
+    } else {
+      crop(m->rows3, m->row3_cnt, max3, 48, m->crops, nullptr, 0, 0);
+      hipLaunchKernelGGL(onet_kernel, dim3(max3, B), dim3(512), (16928 + 14112 + 6912 + 1152) * 4, s, m->crops, m->row3_cnt, m->ow, m->oout);
+    }
+    hipLaunchKernelGGL(stage3_post_kernel, dim3(B), dim3(256), lds_post, s, m->rows3, m->row3_cnt, m->oout, cfg.thresholds[2], 0.7f,
+                       cfg.select_largest, m->fin, m->fin_cnt, m->status);
+    m->last_b = B;
+    hipLaunchKernelGGL(pack_results_kernel, dim3(B), dim3(256), 0, s, m->row_cnt, ncnt, m->fin, m->fin_cnt, B, m->stage);
+    VNF_HIP(hipGetLastError());
+    mark("stage3_post", 0);
+    return VNF_OK;
+  };
+  auto readback = [&]() -> int {
+    VNF_HIP(hipMemcpyAsync(h, m->stage, ((size_t)ncnt + (size_t)B * FIN_FAST * 15) * 4, hipMemcpyDeviceToHost, s));
+    VNF_HIP(hipStreamSynchronize(s));
+    mark("readback", 0);
     const int st = h[cfg.max_batch * 3];
     if (st & (ST_OVER_SCALE | ST_OVER_IMG | ST_OVER_KEEP))
       return fail(VNF_E_CAPACITY, "mtcnn: candidate table overflow (status " + std::to_string(st) + ")");
+    return VNF_OK;
+  };
+  auto counts_of = [&](int base, int& mx, int& tot) {
+    mx = tot = 0;
+    for (int i = 0; i < B; ++i) { mx = std::max(mx, h[base + i]); tot += h[base + i]; }
+  };
+  // an estimate with head room, in whole tiles of the nets' batch dimension
+  auto padded = [&](int v, int limit) { return std::min(limit, ((v + v / 8 + 8 + 15) / 16) * 16); };
+  // Sizes of stages 2 / 3 WITHOUT asking the device (the reference synchronises at both stage boundaries to shape its
+  // tensors, detect_face.py:96-146): a video stream's candidate counts move slowly, so the previous call's counts plus
+  // head room size this call's launches, and the one read-back at the end tells whether they covered it.  If not (or on
+  // the first call of a frame size) stage-1's counts are read and stages 2 / 3 run with exact bounds: stage 2 by its
+  // own counts, stage 3 by stage 2's (it only filters stage-2 rows) -- never a second mid-cascade synchronisation.
+  static const int spec_on = getenv("VNF_MTCNN_SPEC") ? atoi(getenv("VNF_MTCNN_SPEC")) : 1;
+  Mtcnn::Spec& sp = m->spec;
+  int r = VNF_OK;
+  bool exact_needed = true;
+  if (spec_on && sp.valid && sp.b == B && sp.H == H && sp.W == W) {
+    r = stage2(sp.max2, sp.total2);
+    if (r == VNF_OK) r = stage3(sp.max3, sp.total3);
+    if (r == VNF_OK) r = readback();
+    if (r != VNF_OK) return r;
+    int mx2, tot2, mx3, tot3;
+    counts_of(0, mx2, tot2);
+    counts_of(cfg.max_batch, mx3, tot3);
+    exact_needed = mx2 > sp.max2 || tot2 > sp.total2 || mx3 > sp.max3 || tot3 > sp.total3;
+    if (exact_needed) m->spec_misses++;
+  } else {
+    r = read_counts();
+    if (r != VNF_OK) return r;
+    mark("host_sync_1", 0);
+  }
+  if (exact_needed) {
+    // h[0..B) = stage-1 counts (from read_counts, or from the read-back of the speculative pass: stage 1 is not re-run)
+    int mx2, tot2;
+    counts_of(0, mx2, tot2);
+    if (mx2 > 0) {
+      r = stage2(mx2, tot2);
+      if (r == VNF_OK) r = stage3(mx2, tot2);      // stage-3 rows are a subset of stage-2 rows: exact upper bounds
+    } else {
+      m->last_b = B;
+      hipLaunchKernelGGL(pack_results_kernel, dim3(B), dim3(256), 0, s, m->row_cnt, ncnt, m->fin, m->fin_cnt, B, m->stage);
+    }
+    if (r == VNF_OK) r = readback();
+    if (r != VNF_OK) return r;
+  }
+  {
+    int mx2, tot2, mx3, tot3;
+    counts_of(0, mx2, tot2);
+    counts_of(cfg.max_batch, mx3, tot3);
+    sp.valid = true; sp.b = B; sp.H = H; sp.W = W;
+    sp.max2 = padded(mx2, KEEP); sp.total2 = padded(tot2, B * KEEP);
+    sp.max3 = padded(mx3, KEEP); sp.total3 = padded(tot3, B * KEEP);
   }
   int maxf = 0;
   for (int i = 0; i < B; ++i) { cnt[i] = h[2 * cfg.max_batch + i]; maxf = std::max(maxf, cnt[i]); }

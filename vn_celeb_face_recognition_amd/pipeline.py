@@ -144,11 +144,12 @@ def recognize_celeb(bth_alg_face_list, device, emb_model, classify_model, transf
 class Ticket:
     """One submitted frame batch (FacePipeline.submit).  `done` is set once detection has finished on the host and
     the embedding work is enqueued; the embeddings / classes are produced on the pipeline's embedding stream."""
-    __slots__ = ("counts", "boxes", "probs", "points", "emb", "amax", "prob", "event", "done", "error", "_slice", "_pipe")
+    __slots__ = ("counts", "boxes", "probs", "points", "emb", "amax", "prob", "event", "done", "error", "_slice", "_pipe", "upload_slot")
 
     def __init__(self):
         self.counts = self.boxes = self.probs = self.points = None
         self.emb = self.amax = self.prob = self.event = self.error = self._slice = self._pipe = None
+        self.upload_slot = -1
         self.done = threading.Event()
 
     def wait_host(self):

@@ -101,7 +101,7 @@ def run_stream(source, pipe, n_frames, rank=0, world=1, device=None, on_frame=No
         from .streams import side_stream
         from .upload import FrameUploader
         comm = side_stream(dev, 7)          # the collective's stream (roles 0..6 belong to the pipeline, streams.py)
-        uploader = FrameUploader(dev, depth=lag + 2)
+        uploader = FrameUploader(dev, depth=lag + 3)
     cap = int(cap) if cap else max(256, 16 * int(n_frames))
     WIDTH = 517                             # 512 embedding + 4 box + 1 frame slot
     classify_here = rank == 0 or on_frame is not None
@@ -128,6 +128,10 @@ def run_stream(source, pipe, n_frames, rank=0, world=1, device=None, on_frame=No
         n, payload = 0, None
         if t is not None:
             counts, boxes, emb, _, _ = t.result()
+            if uploader is not None:
+                # the batch's frames were last read by its warp, which precedes its embedding event (a batch without
+                # faces: by its detection, whose read-back the host has already waited for)
+                uploader.release(getattr(t, "upload_slot", -1), getattr(t, "event", None))
             n = int(sum(counts))
             if n:
                 slot = np.repeat(np.arange(len(counts)), counts).astype(np.float32)   # frame slot inside the batch
@@ -224,13 +228,26 @@ def run_stream(source, pipe, n_frames, rank=0, world=1, device=None, on_frame=No
         while len(pending) > 1:
             consume(pending.pop(0))
 
+    def uploads():
+        """this rank's batches with the upload one batch AHEAD: submit() blocks on the detector's single read-back, so
+        the next batch's host -> HBM copy has to be in flight before it, or copy and detection would take turns"""
+        it = source.rank_batches(n_frames, rank, world)
+        nxt = next(it, None)
+        up = (uploader.upload(nxt[1]) + (uploader.last_slot,)) if (nxt is not None and uploader is not None) else None
+        while nxt is not None:
+            cur, cur_up = nxt, up
+            nxt = next(it, None)
+            up = (uploader.upload(nxt[1]) + (uploader.last_slot,)) if (nxt is not None and uploader is not None) else None
+            yield cur, cur_up
+
     rounds = 0
-    for b, q, inf in source.rank_batches(n_frames, rank, world):
+    for (b, q, inf), up in uploads():
         if state["shape"] is None:
             state["shape"] = q[0].shape                       # frames of one stream share a shape
-        if uploader is not None:
-            frames_dev, ready = uploader.upload(q)
+        if up is not None:
+            frames_dev, ready, slot = up
             ticket = pipe.submit(frames_dev, classify=False, ready=ready)
+            ticket.upload_slot = slot
         else:
             frames_dev, _ = pipe.detector._to_device_frames(q)
             ticket = pipe.submit(frames_dev, classify=False)
