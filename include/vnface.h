@@ -146,12 +146,13 @@ typedef struct {
   int32_t select_largest;  /* mtcnn.py:203: order boxes by area, descending */
   int32_t max_batch;       /* frames per call */
   int32_t max_height, max_width;
-  int32_t max_candidates;  /* stage-1 candidates (P-Net cells above thresholds[0]) per (pyramid level, frame): 0 = 8192
-                            * when every level has fewer than 2^19 P-Net cells (1080p at any min_face_size), else 4096;
-                            * a value in (0, 4096] selects the 4096-entry table.  The other tables are compile-time
-                            * sized: 8192 candidates per frame into the cross-scale NMS, 2048 survivors per NMS, stage and
-                            * frame.  A frame that exceeds any of them fails the call with VNF_E_CAPACITY (never a
-                            * silent truncation) */
+  int32_t max_candidates;  /* rows per frame of the stage-2 / stage-3 candidate tables (survivors of the cross-scale NMS,
+                            * of the R-Net filter and of the O-Net filter): 0 or anything <= 2048 = 2048.  The reference
+                            * has no cap (detect_face.py:79-93,203-218).  Here stage 1 is sized by the pyramid itself
+                            * (every P-Net cell has a slot: it cannot overflow) and every NMS moves from LDS to
+                            * global-memory scratch when a list outgrows the LDS tables, so this is the ONLY bound: a
+                            * frame with more stage-1 survivors fails the call with VNF_E_CAPACITY (never a silent
+                            * truncation) and the host layer re-creates the handle with a larger table and retries */
 } vnf_mtcnn_cfg;
 
 int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const vnf_tensor_desc* rnet, int n_rnet,

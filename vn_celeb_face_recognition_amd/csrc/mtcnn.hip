@@ -37,11 +37,14 @@ namespace vnf {
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
 constexpr int MAX_LEVELS = 24;
-constexpr int CAP_SCALE = 4096;  // candidates per (level, frame) before NMS: the default of the run-time capacity (12-bit slot in
-                                 // the sort key); 8192 (13-bit slot) when every level has fewer than 2^19 P-Net cells, vnf_mtcnn_cfg.max_candidates
-constexpr int CAP_SCALE_MAX = 8192;
-constexpr int CAP_IMG = 8192;    // candidates per frame entering the cross-scale NMS
-constexpr int KEEP = 2048;       // survivors per frame after any NMS pass (stage-2 / stage-3 table rows)
+// Candidate tables.  Stage 1 is sized by the pyramid itself: every (level, frame) list has room for all cells of the
+// level, so it cannot overflow.  The stage-2 / stage-3 tables hold `keep` rows per frame, a RUN-TIME capacity
+// (vnf_mtcnn_cfg.max_candidates, default KEEP).  The NMS kernels keep their sort keys and kept boxes in LDS while a
+// list fits the constants below and switch to global-memory scratch beyond them -- the reference has no cap at all
+// (detect_face.py:79-93,203-218) and neither has the arithmetic here; only the row tables of stages 2 / 3 are bounded,
+// by a capacity the caller can raise (the host layer grows it and retries on VNF_E_CAPACITY).
+constexpr int CAP_LDS_KEYS = 8192;   // sort keys held in LDS by the stage-1 NMS kernels
+constexpr int KEEP = 2048;           // kept boxes / post-kernel keys held in LDS; default rows per frame of the stage tables
 
 
 struct LevelDesc {
@@ -472,8 +475,8 @@ __global__ void pnet_conv2_kernel(const float* __restrict__ p1, LevelTable t, PN
 // mtcnn.py:44-49: conv3 16->32 + PReLU, conv4_1 (1x1 ->2) + softmax, conv4_2 (1x1 -> 4);
 // detect_face.py:209: mask = prob[:,1] >= thr, fused: survivors are appended to the
 // (level, frame) candidate list.  prob_dbg / reg_dbg (optional) receive the dense maps.
-__global__ void pnet_conv3_heads_kernel(const float* __restrict__ c2, LevelTable t, PNetW w, float thr, int B, int cap_scale,
-                                        Cand* __restrict__ cand, int* __restrict__ cand_cnt, int* __restrict__ status,
+__global__ void pnet_conv3_heads_kernel(const float* __restrict__ c2, LevelTable t, PNetW w, float thr, int B, int cap_out,
+                                        Cand* __restrict__ cand, int* __restrict__ cells, int* __restrict__ cand_cnt,
                                         float* __restrict__ prob_dbg, float* __restrict__ reg_dbg) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= t.tot_out) return;
@@ -524,15 +527,13 @@ __global__ void pnet_conv3_heads_kernel(const float* __restrict__ c2, LevelTable
     rd[0] = r0; rd[(size_t)t.tot_out] = r1; rd[2 * (size_t)t.tot_out] = r2; rd[3 * (size_t)t.tot_out] = r3;
   }
   if (prob >= thr) {
-    const int seg = li * B + img;
-    const int slot = atomicAdd(&cand_cnt[seg], 1);
-    if (slot < cap_scale) {
-      Cand c;
-      c.score = prob; c.r0 = r0; c.r1 = r1; c.r2 = r2; c.r3 = r3; c.cell = p;
-      cand[(size_t)seg * cap_scale + slot] = c;
-    } else {
-      atomicOr(status, ST_OVER_SCALE);
-    }
+    // the record goes to its cell's slot of a dense per-frame table, the cell index to the level's compact list (one
+    // entry per cell at most: the list cannot overflow)
+    const int slot = atomicAdd(&cand_cnt[li * B + img], 1);
+    Cand c;
+    c.score = prob; c.r0 = r0; c.r1 = r1; c.r2 = r2; c.r3 = r3; c.cell = p;
+    cand[(size_t)img * cap_out + idx] = c;
+    cells[(size_t)img * cap_out + L.off_out + slot] = p;
   }
 }
 
@@ -547,37 +548,57 @@ __device__ __forceinline__ float4 cell_box(int cell, int ow, float scale) {
 // --------------------------------------------------------------------------------------------- K4a
 // detect_face.py:79: batched_nms(..., 0.5) within each (scale, image).  Visiting order = stable
 // score-descending over nonzero() order (y, x): key = (inverted score | cell | slot).
-__global__ void __launch_bounds__(256) nms_scale_kernel(const Cand* __restrict__ cand, const int* __restrict__ cand_cnt,
-                                                         LevelTable t, int B, float thr, Cand* __restrict__ keep,
-                                                         int* __restrict__ keep_cnt, int* __restrict__ status, int cap_scale) {
+// global-memory fallback of the NMS kernels (per frame `stride` entries; a level's region starts at its off_out)
+struct NmsScratch {
+  unsigned long long* keys;
+  float4* kbox;
+  int* keep;
+  float4* reg;
+  int stride;
+};
+
+template <bool KEYS_G, bool KEPT_G>
+__device__ __forceinline__ void nms_scale_body(const Cand* __restrict__ cd, const int* __restrict__ cl, int n, int ow, float scale,
+                                               float thr, unsigned long long* keys, float4* kbox, int* keepl, float4* s_cbox,
+                                               int* s_alive, int* __restrict__ out_cells, int* __restrict__ out_cnt, int* status) {
+  const int npad = next_pow2(n);
+  // visiting order = stable score-descending over nonzero() order (y, x): key = (inverted score | cell); cells are unique
+  for (int i = threadIdx.x; i < npad; i += blockDim.x)
+    keys[i] = i < n ? ((unsigned long long)inv_score_bits(cd[cl[i]].score) << 32) | (unsigned)cl[i] : ~0ull;
+  __syncthreads();
+  block_sort(keys, n, npad);
+  auto getbox = [&](int r) { return cell_box((int)(keys[r] & 0xFFFFFFFFu), ow, scale); };
+  const int nk = block_greedy_nms<NMS_TV>(n, thr, getbox, keepl, kbox, n, s_cbox, s_alive, status);
+  for (int k = threadIdx.x; k < nk; k += blockDim.x) out_cells[k] = (int)(keys[keepl[k]] & 0xFFFFFFFFu);
+  if (threadIdx.x == 0) *out_cnt = nk;
+}
+
+__global__ void __launch_bounds__(256) nms_scale_kernel(const Cand* __restrict__ cand, const int* __restrict__ cells,
+                                                         const int* __restrict__ cand_cnt, LevelTable t, int B, int cap_out, float thr,
+                                                         int* __restrict__ keep1c, int* __restrict__ keep_cnt, int* __restrict__ status,
+                                                         NmsScratch g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);           // cap_scale * 8
-  float4* s_kbox = reinterpret_cast<float4*>(smem + cap_scale * 8);                  // KEEP * 16
-  int* s_keep = reinterpret_cast<int*>(smem + cap_scale * 8 + KEEP * 16);            // KEEP * 4
-  float4* s_cbox = reinterpret_cast<float4*>(smem + cap_scale * 8 + KEEP * 20);      // 256 * 16
-  int* s_alive = reinterpret_cast<int*>(smem + cap_scale * 8 + KEEP * 20 + 256 * 16);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);              // CAP_LDS_KEYS * 8
+  float4* s_kbox = reinterpret_cast<float4*>(smem + CAP_LDS_KEYS * 8);                  // KEEP * 16
+  int* s_keep = reinterpret_cast<int*>(smem + CAP_LDS_KEYS * 8 + KEEP * 16);            // KEEP * 4
+  float4* s_cbox = reinterpret_cast<float4*>(smem + CAP_LDS_KEYS * 8 + KEEP * 20);      // 256 * 16
+  int* s_alive = reinterpret_cast<int*>(smem + CAP_LDS_KEYS * 8 + KEEP * 20 + 256 * 16);
   const int li = blockIdx.x, img = blockIdx.y, seg = li * B + img;
-  const int sbits = cap_scale > 4096 ? 13 : 12;                                      // slot bits of the key (cell < 2^(32 - sbits))
-  const unsigned smask = (1u << sbits) - 1u;
-  const int n = min(cand_cnt[seg], cap_scale);
+  const int n = cand_cnt[seg];
   if (n == 0) {
     if (threadIdx.x == 0) keep_cnt[seg] = 0;
     return;
   }
-  const Cand* c = cand + (size_t)seg * cap_scale;
-  const int npad = next_pow2(n);
-  for (int i = threadIdx.x; i < npad; i += blockDim.x)
-    keys[i] = i < n ? ((unsigned long long)inv_score_bits(c[i].score) << 32) | ((unsigned long long)(unsigned)c[i].cell << sbits) | (unsigned)i
-                    : ~0ull;
-  __syncthreads();
-  block_sort(keys, n, npad);
-  const int ow = t.l[li].ow;
-  const float scale = t.l[li].scale;
-  auto getbox = [&](int r) { return cell_box(c[(int)(keys[r] & smask)].cell, ow, scale); };
-  const int nk = block_greedy_nms<NMS_TV>(n, thr, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
-  Cand* o = keep + (size_t)seg * KEEP;
-  for (int k = threadIdx.x; k < nk; k += blockDim.x) o[k] = c[(int)(keys[s_keep[k]] & smask)];
-  if (threadIdx.x == 0) keep_cnt[seg] = nk;
+  const LevelDesc& L = t.l[li];
+  const size_t base = (size_t)img * cap_out + L.off_out;
+  const Cand* cd = cand + base;
+  const int* cl = cells + base;
+  int* oc = keep1c + base;
+  const size_t gb = (size_t)img * g.stride + L.off_out;
+  // LDS while the list fits; a level with more candidates than the LDS tables hold takes global-memory scratch
+  if (n <= KEEP) nms_scale_body<false, false>(cd, cl, n, L.ow, L.scale, thr, keys, s_kbox, s_keep, s_cbox, s_alive, oc, keep_cnt + seg, status);
+  else if (n <= CAP_LDS_KEYS) nms_scale_body<false, true>(cd, cl, n, L.ow, L.scale, thr, keys, g.kbox + gb, g.keep + gb, s_cbox, s_alive, oc, keep_cnt + seg, status);
+  else nms_scale_body<true, true>(cd, cl, n, L.ow, L.scale, thr, g.keys + gb, g.kbox + gb, g.keep + gb, s_cbox, s_alive, oc, keep_cnt + seg, status);
 }
 
 // --------------------------------------------------------------------------------------------- K4b
@@ -600,36 +621,10 @@ __device__ __forceinline__ void rerec_pad(float& x1, float& y1, float& x2, float
   r.x = ix; r.y = iy; r.ex = iex; r.ey = iey;
 }
 
-__global__ void __launch_bounds__(256) nms_image_kernel(const Cand* __restrict__ keep1, const int* __restrict__ keep1_cnt,
-                                                         LevelTable t, int B, float thr, int W, int H,
-                                                         Row* __restrict__ rows, int* __restrict__ row_cnt,
-                                                         int* __restrict__ status) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);           // CAP_IMG * 8
-  float4* s_kbox = reinterpret_cast<float4*>(smem + CAP_IMG * 8);
-  int* s_keep = reinterpret_cast<int*>(smem + CAP_IMG * 8 + KEEP * 16);
-  float4* s_cbox = reinterpret_cast<float4*>(smem + CAP_IMG * 8 + KEEP * 20);
-  int* s_alive = reinterpret_cast<int*>(smem + CAP_IMG * 8 + KEEP * 20 + 256 * 16);
-  __shared__ int s_off[MAX_LEVELS + 1];
-  const int img = blockIdx.x;
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int l = 0; l < t.n; ++l) { s_off[l] = acc; acc += keep1_cnt[l * B + img]; }
-    s_off[t.n] = acc;
-    if (acc > CAP_IMG) atomicOr(status, ST_OVER_IMG);
-  }
-  __syncthreads();
-  const int n = min(s_off[t.n], CAP_IMG);
-  if (n == 0) {
-    if (threadIdx.x == 0) row_cnt[img] = 0;
-    return;
-  }
-  auto locate = [&](int g, int& l) -> const Cand* {  // gathered index -> record
-    l = 0;
-    for (int i = 1; i < t.n; ++i)
-      if (g >= s_off[i]) l = i;
-    return keep1 + (size_t)(l * B + img) * KEEP + (g - s_off[l]);
-  };
+template <bool KEYS_G, bool KEPT_G, typename Locate>
+__device__ __forceinline__ void nms_image_body(Locate locate, const LevelTable& t, int n, float thr, int W, int H, int KR,
+                                               unsigned long long* keys, float4* kbox, int* keepl, float4* s_cbox, int* s_alive,
+                                               Row* __restrict__ rows_img, int* __restrict__ row_cnt_img, int* status) {
   const int npad = next_pow2(n);
   for (int i = threadIdx.x; i < npad; i += blockDim.x) {
     if (i < n) {
@@ -647,19 +642,60 @@ __global__ void __launch_bounds__(256) nms_image_kernel(const Cand* __restrict__
     const Cand* c = locate((int)(keys[r] & 0xFFFFFFFFu), l);
     return cell_box(c->cell, t.l[l].ow, t.l[l].scale);
   };
-  const int nk = block_greedy_nms<NMS_TV>(n, thr, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
+  int nk = block_greedy_nms<NMS_TV>(n, thr, getbox, keepl, kbox, n, s_cbox, s_alive, status);
+  if (nk > KR) {     // more survivors than the stage-2 table has rows: the call fails (the host layer grows the table)
+    if (threadIdx.x == 0) atomicOr(status, ST_OVER_KEEP);
+    nk = KR;
+  }
   for (int k = threadIdx.x; k < nk; k += blockDim.x) {
     int l;
-    const Cand* c = locate((int)(keys[s_keep[k]] & 0xFFFFFFFFu), l);
-    const float4 b = s_kbox[k];
+    const Cand* c = locate((int)(keys[keepl[k]] & 0xFFFFFFFFu), l);
+    const float4 b = kbox[k];
     const float regw = b.z - b.x, regh = b.w - b.y;
     float x1 = b.x + c->r0 * regw, y1 = b.y + c->r1 * regh, x2 = b.z + c->r2 * regw, y2 = b.w + c->r3 * regh;
     Row r;
     rerec_pad(x1, y1, x2, y2, W, H, r);
     r.score = c->score;
-    rows[(size_t)img * KEEP + k] = r;
+    rows_img[k] = r;
   }
-  if (threadIdx.x == 0) row_cnt[img] = nk;
+  if (threadIdx.x == 0) *row_cnt_img = nk;
+}
+
+__global__ void __launch_bounds__(256) nms_image_kernel(const Cand* __restrict__ cand, const int* __restrict__ keep1c,
+                                                         const int* __restrict__ keep1_cnt, LevelTable t, int B, int cap_out,
+                                                         float thr, int W, int H, int KR, Row* __restrict__ rows,
+                                                         int* __restrict__ row_cnt, int* __restrict__ status, NmsScratch g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);           // CAP_LDS_KEYS * 8
+  float4* s_kbox = reinterpret_cast<float4*>(smem + CAP_LDS_KEYS * 8);
+  int* s_keep = reinterpret_cast<int*>(smem + CAP_LDS_KEYS * 8 + KEEP * 16);
+  float4* s_cbox = reinterpret_cast<float4*>(smem + CAP_LDS_KEYS * 8 + KEEP * 20);
+  int* s_alive = reinterpret_cast<int*>(smem + CAP_LDS_KEYS * 8 + KEEP * 20 + 256 * 16);
+  __shared__ int s_off[MAX_LEVELS + 1];
+  const int img = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int l = 0; l < t.n; ++l) { s_off[l] = acc; acc += keep1_cnt[l * B + img]; }
+    s_off[t.n] = acc;
+  }
+  __syncthreads();
+  const int n = s_off[t.n];
+  if (n == 0) {
+    if (threadIdx.x == 0) row_cnt[img] = 0;
+    return;
+  }
+  const size_t base = (size_t)img * cap_out;
+  auto locate = [&](int gi, int& l) -> const Cand* {  // gathered index -> record (per-scale survivors are lists of cells)
+    l = 0;
+    for (int i = 1; i < t.n; ++i)
+      if (gi >= s_off[i]) l = i;
+    return cand + base + t.l[l].off_out + keep1c[base + t.l[l].off_out + (gi - s_off[l])];
+  };
+  Row* ro = rows + (size_t)img * KR;
+  const size_t gb = (size_t)img * g.stride;
+  if (n <= KEEP) nms_image_body<false, false>(locate, t, n, thr, W, H, KR, keys, s_kbox, s_keep, s_cbox, s_alive, ro, row_cnt + img, status);
+  else if (n <= CAP_LDS_KEYS) nms_image_body<false, true>(locate, t, n, thr, W, H, KR, keys, g.kbox + gb, g.keep + gb, s_cbox, s_alive, ro, row_cnt + img, status);
+  else nms_image_body<true, true>(locate, t, n, thr, W, H, KR, g.keys + gb, g.kbox + gb, g.keep + gb, s_cbox, s_alive, ro, row_cnt + img, status);
 }
 
 // --------------------------------------------------------------------------------------------- K5
@@ -673,8 +709,8 @@ struct CropDst {
   float* base;      // nullptr: candidate not in this chunk
   int cs, ps;       // channel stride, pixel stride (floats)
 };
-__device__ __forceinline__ CropDst crop_dst(float* out, const int* offs, int c0, int cap, int img, int k, int S) {
-  if (!offs) return CropDst{out + ((size_t)img * KEEP + k) * 3 * S * S, S * S, 1};
+__device__ __forceinline__ CropDst crop_dst(float* out, const int* offs, int c0, int cap, int img, int k, int S, int KR) {
+  if (!offs) return CropDst{out + ((size_t)img * KR + k) * 3 * S * S, S * S, 1};
   const int ci = offs[img] + k - c0;
   if (ci < 0 || ci >= cap) return CropDst{nullptr, 0, 0};
   return CropDst{out + (size_t)ci * S * S * 4, 1, 4};
@@ -683,12 +719,12 @@ __device__ __forceinline__ CropDst crop_dst(float* out, const int* offs, int c0,
 __global__ void __launch_bounds__(256) crop_resize_kernel(const uint8_t* __restrict__ frames, int H, int W,
                                                            const Row* __restrict__ rows, const int* __restrict__ row_cnt,
                                                            int S, float* __restrict__ out, int* __restrict__ status,
-                                                           const int* __restrict__ offs, int c0, int cap) {
+                                                           const int* __restrict__ offs, int c0, int cap, int KR) {
   const int k = blockIdx.x, img = blockIdx.y;
   if (k >= row_cnt[img]) return;
-  const CropDst d = crop_dst(out, offs, c0, cap, img, k, S);
+  const CropDst d = crop_dst(out, offs, c0, cap, img, k, S, KR);
   if (!d.base) return;
-  const Row r = rows[(size_t)img * KEEP + k];
+  const Row r = rows[(size_t)img * KR + k];
   const int y0 = r.y - 1, x0 = r.x - 1, ch = r.ey - y0, cw = r.ex - x0;
   float* o = d.base;
   if (d.ps == 4 && blockIdx.z == 0)
@@ -728,15 +764,15 @@ constexpr int CROP_MAXB = 4096;  // bytes of crop row per strip (1365 px)
 __global__ void __launch_bounds__(256) crop_resize_rows_kernel(const uint8_t* __restrict__ frames, int H, int W,
                                                                 const Row* __restrict__ rows, const int* __restrict__ row_cnt,
                                                                 int S, float* __restrict__ out, int* __restrict__ status,
-                                                                const int* __restrict__ offs, int c0, int cap) {
+                                                                const int* __restrict__ offs, int c0, int cap, int KR) {
   // per-byte column sums of one bin row are at most (rows of a bin) x 255: 16 bits hold 257 rows, deeper bins (frames
   // taller than ~6000 px at S = 24) take the per-pixel path.  Half the LDS of 32-bit sums -> twice the resident waves.
   __shared__ __attribute__((aligned(16))) unsigned short strips[4][CROP_MAXB + 32];
   const int k = blockIdx.x, img = blockIdx.y;
   if (k >= row_cnt[img]) return;
-  const CropDst d = crop_dst(out, offs, c0, cap, img, k, S);
+  const CropDst d = crop_dst(out, offs, c0, cap, img, k, S, KR);
   if (!d.base) return;
-  const Row r = rows[(size_t)img * KEEP + k];
+  const Row r = rows[(size_t)img * KR + k];
   const int y0 = r.y - 1, x0 = r.x - 1, ch = r.ey - y0, cw = r.ex - x0;
   float* o = d.base;
   if (d.ps == 4 && blockIdx.z == 0)
@@ -1192,14 +1228,14 @@ __global__ void prefix_offsets_kernel(const int* __restrict__ cnt, int B, int* _
 // head outputs of the MFMA plans (hw floats per candidate: a0, a1, then the regression / landmark
 // values) -> the per-frame tables the post kernels read: [softmax prob of class 1, values...]
 __global__ void heads_scatter_kernel(const float* __restrict__ heads, int hw, const int* __restrict__ offs,
-                                     const int* __restrict__ cnt, int c0, int cap, float* __restrict__ dst, int nf, int split) {
+                                     const int* __restrict__ cnt, int c0, int cap, float* __restrict__ dst, int nf, int split, int KR) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x, img = blockIdx.y;
   if (k >= cnt[img]) return;
   const int ci = offs[img] + k - c0;
   if (ci < 0 || ci >= cap) return;
   const float* hsrc = heads + (size_t)ci * hw;
   auto val = [&](int i) { return split ? (float)__builtin_bit_cast(sf16, hsrc[i]) : hsrc[i]; };
-  float* o = dst + ((size_t)img * KEEP + k) * nf;
+  float* o = dst + ((size_t)img * KR + k) * nf;
   const float a0 = val(0), a1 = val(1);
   const float m = fmaxf(a0, a1);
   const float e0 = expf(a0 - m), e1 = expf(a1 - m);
@@ -1302,21 +1338,12 @@ __global__ void __launch_bounds__(512) onet_kernel(const float* __restrict__ cro
 // --------------------------------------------------------------------------------------------- stage-2 post
 // detect_face.py:119-131: keep score > thr, batched_nms(0.7) per image, bbreg (w,h WITH +1), rerec;
 // then pad for stage 3 (136).  Visiting order: score descending, ties by stage-1 table order.
-__global__ void __launch_bounds__(256) stage2_post_kernel(const Row* __restrict__ rows, const int* __restrict__ row_cnt,
-                                                           const float* __restrict__ rout, float thr_score, float thr_nms,
-                                                           int W, int H, Row* __restrict__ rows3, int* __restrict__ row3_cnt,
-                                                           int* __restrict__ status) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // KEEP * 8
-  float4* s_kbox = reinterpret_cast<float4*>(smem + KEEP * 8);
-  int* s_keep = reinterpret_cast<int*>(smem + KEEP * 8 + KEEP * 16);
-  float4* s_cbox = reinterpret_cast<float4*>(smem + KEEP * 28);
-  int* s_alive = reinterpret_cast<int*>(smem + KEEP * 28 + 256 * 16);
+template <bool BIG>
+__device__ __forceinline__ void stage2_post_body(const Row* __restrict__ r, const float* __restrict__ ro, int n0, float thr_score,
+                                                 float thr_nms, int W, int H, unsigned long long* keys, float4* kbox, int* keepl,
+                                                 float4* s_cbox, int* s_alive, Row* __restrict__ out, int* __restrict__ out_cnt,
+                                                 int* status) {
   __shared__ int s_n;
-  const int img = blockIdx.x;
-  const int n0 = row_cnt[img];
-  const Row* r = rows + (size_t)img * KEEP;
-  const float* ro = rout + (size_t)img * KEEP * 5;
   const int npad = next_pow2(max(n0, 1));
   for (int i = threadIdx.x; i < npad; i += blockDim.x)
     keys[i] = (i < n0 && ro[i * 5] > thr_score) ? ((unsigned long long)inv_score_bits(ro[i * 5]) << 32) | (unsigned)i : ~0ull;
@@ -1330,19 +1357,39 @@ __global__ void __launch_bounds__(256) stage2_post_kernel(const Row* __restrict_
   __syncthreads();
   const int n = s_n;
   auto getbox = [&](int q) { const Row& b = r[(int)(keys[q] & 0xFFFFFFFFu)]; return float4{b.x1, b.y1, b.x2, b.y2}; };
-  const int nk = block_greedy_nms<NMS_TV>(n, thr_nms, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
+  const int nk = block_greedy_nms<NMS_TV>(n, thr_nms, getbox, keepl, kbox, max(n, 1), s_cbox, s_alive, status);
   for (int k = threadIdx.x; k < nk; k += blockDim.x) {
-    const int src = (int)(keys[s_keep[k]] & 0xFFFFFFFFu);
-    const float4 b = s_kbox[k];
+    const int src = (int)(keys[keepl[k]] & 0xFFFFFFFFu);
+    const float4 b = kbox[k];
     const float* mv = ro + src * 5 + 1;
     const float w = b.z - b.x + 1.f, h = b.w - b.y + 1.f;
     float x1 = b.x + mv[0] * w, y1 = b.y + mv[1] * h, x2 = b.z + mv[2] * w, y2 = b.w + mv[3] * h;
     Row o;
     rerec_pad(x1, y1, x2, y2, W, H, o);
     o.score = ro[src * 5];
-    rows3[(size_t)img * KEEP + k] = o;
+    out[k] = o;
   }
-  if (threadIdx.x == 0) row3_cnt[img] = nk;
+  if (threadIdx.x == 0) *out_cnt = nk;
+}
+
+__global__ void __launch_bounds__(256) stage2_post_kernel(const Row* __restrict__ rows, const int* __restrict__ row_cnt,
+                                                           const float* __restrict__ rout, float thr_score, float thr_nms,
+                                                           int W, int H, int KR, Row* __restrict__ rows3, int* __restrict__ row3_cnt,
+                                                           int* __restrict__ status, NmsScratch g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // KEEP * 8
+  float4* s_kbox = reinterpret_cast<float4*>(smem + KEEP * 8);
+  int* s_keep = reinterpret_cast<int*>(smem + KEEP * 8 + KEEP * 16);
+  float4* s_cbox = reinterpret_cast<float4*>(smem + KEEP * 28);
+  int* s_alive = reinterpret_cast<int*>(smem + KEEP * 28 + 256 * 16);
+  const int img = blockIdx.x;
+  const int n0 = row_cnt[img];
+  const Row* r = rows + (size_t)img * KR;
+  const float* ro = rout + (size_t)img * KR * 5;
+  Row* out = rows3 + (size_t)img * KR;     // survivors are a subset of the n0 <= KR input rows: no overflow
+  const size_t gb = (size_t)img * g.stride;
+  if (n0 <= KEEP) stage2_post_body<false>(r, ro, n0, thr_score, thr_nms, W, H, keys, s_kbox, s_keep, s_cbox, s_alive, out, row3_cnt + img, status);
+  else stage2_post_body<true>(r, ro, n0, thr_score, thr_nms, W, H, g.keys + gb, g.kbox + gb, g.keep + gb, s_cbox, s_alive, out, row3_cnt + img, status);
 }
 
 // --------------------------------------------------------------------------------------------- K7
@@ -1351,27 +1398,17 @@ __global__ void __launch_bounds__(256) stage2_post_kernel(const Row* __restrict_
 // are visited in table order: the reference leaves tie order to np.argsort's unstable default
 // sort, which is implementation defined; the oracle pins the same rule), then mtcnn.py:334-340: order by box area
 // descending (argsort ascending, reversed).  fin: [x1,y1,x2,y2,score, 10 landmark coords] rows.
-__global__ void __launch_bounds__(256) stage3_post_kernel(const Row* __restrict__ rows3, const int* __restrict__ row3_cnt,
-                                                           const float* __restrict__ oout, float thr_score, float thr_nms,
-                                                           int select_largest, float* __restrict__ fin,
-                                                           int* __restrict__ fin_cnt, int* __restrict__ status) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
-  float4* s_kbox = reinterpret_cast<float4*>(smem + KEEP * 8);
-  int* s_keep = reinterpret_cast<int*>(smem + KEEP * 8 + KEEP * 16);
-  float4* s_cbox = reinterpret_cast<float4*>(smem + KEEP * 28);
-  int* s_alive = reinterpret_cast<int*>(smem + KEEP * 28 + 256 * 16);
-  float4* s_reg = reinterpret_cast<float4*>(smem + KEEP * 28 + 256 * 20);  // KEEP * 16: boxes after bbreg
+template <bool BIG>
+__device__ __forceinline__ void stage3_post_body(const Row* __restrict__ r, const float* __restrict__ oo, int n0, float thr_score,
+                                                 float thr_nms, int select_largest, unsigned long long* keys, float4* kbox,
+                                                 int* keepl, float4* reg, float4* s_cbox, int* s_alive, float* __restrict__ fo,
+                                                 int* __restrict__ out_cnt, int* status) {
   __shared__ int s_n;
-  const int img = blockIdx.x;
-  const int n0 = row3_cnt[img];
-  const Row* r = rows3 + (size_t)img * KEEP;
-  const float* oo = oout + (size_t)img * KEEP * 15;
   for (int i = threadIdx.x; i < n0; i += blockDim.x) {  // bbreg of every row (w,h WITH +1)
     const Row& b = r[i];
     const float* mv = oo + i * 15 + 1;
     const float w = b.x2 - b.x1 + 1.f, h = b.y2 - b.y1 + 1.f;
-    s_reg[i] = float4{b.x1 + mv[0] * w, b.y1 + mv[1] * h, b.x2 + mv[2] * w, b.y2 + mv[3] * h};
+    reg[i] = float4{b.x1 + mv[0] * w, b.y1 + mv[1] * h, b.x2 + mv[2] * w, b.y2 + mv[3] * h};
   }
   const int npad = next_pow2(max(n0, 1));
   for (int i = threadIdx.x; i < npad; i += blockDim.x)  // ties: earlier row first (see header note on ties)
@@ -1386,17 +1423,17 @@ __global__ void __launch_bounds__(256) stage3_post_kernel(const Row* __restrict_
   __syncthreads();
   const int n = s_n;
   auto srcof = [&](int q) { return (int)(keys[q] & 0xFFFFFFFFu); };
-  auto getbox = [&](int q) { return s_reg[srcof(q)]; };
-  const int nk = block_greedy_nms<NMS_MIN>(n, thr_nms, getbox, s_keep, s_kbox, KEEP, s_cbox, s_alive, status);
+  auto getbox = [&](int q) { return reg[srcof(q)]; };
+  const int nk = block_greedy_nms<NMS_MIN>(n, thr_nms, getbox, keepl, kbox, max(n, 1), s_cbox, s_alive, status);
   __syncthreads();
   // final order: area descending (argsort ascending reversed: ties -> later pick first)
   // the score-sorted keys are dead after this: resolve kept ranks to source rows, then reuse `keys`
-  for (int k = threadIdx.x; k < nk; k += blockDim.x) s_keep[k] = srcof(s_keep[k]);
+  for (int k = threadIdx.x; k < nk; k += blockDim.x) keepl[k] = srcof(keepl[k]);
   __syncthreads();
   const int kpad = next_pow2(max(nk, 1));
   for (int k = threadIdx.x; k < kpad; k += blockDim.x) {
     if (k < nk) {
-      const float4 b = s_kbox[k];
+      const float4 b = kbox[k];
       const float area = (b.z - b.x) * (b.w - b.y);
       // areas may be negative in degenerate cases: map float to an order-preserving unsigned
       unsigned u = __float_as_uint(area);
@@ -1409,12 +1446,11 @@ __global__ void __launch_bounds__(256) stage3_post_kernel(const Row* __restrict_
   }
   __syncthreads();
   block_sort(keys, nk, kpad);
-  float* fo = fin + (size_t)img * KEEP * 15;
   for (int q = threadIdx.x; q < nk; q += blockDim.x) {
     const int k = select_largest ? 0x7FFFFFFF - (int)(keys[q] & 0xFFFFFFFFu) : (int)keys[q];
-    const int src = s_keep[k];
+    const int src = keepl[k];
     const Row& b = r[src];
-    const float4 bb = s_kbox[k];
+    const float4 bb = kbox[k];
     float* o = fo + q * 15;
     o[0] = bb.x; o[1] = bb.y; o[2] = bb.z; o[3] = bb.w; o[4] = oo[src * 15];
     // detect_face.py:159-163 (boxes BEFORE bbreg): px = w_i * p + x1 - 1
@@ -1425,7 +1461,28 @@ __global__ void __launch_bounds__(256) stage3_post_kernel(const Row* __restrict_
       o[6 + 2 * j] = h_i * lm[5 + j] + b.y1 - 1.f;
     }
   }
-  if (threadIdx.x == 0) fin_cnt[img] = nk;
+  if (threadIdx.x == 0) *out_cnt = nk;
+}
+
+__global__ void __launch_bounds__(256) stage3_post_kernel(const Row* __restrict__ rows3, const int* __restrict__ row3_cnt,
+                                                           const float* __restrict__ oout, float thr_score, float thr_nms,
+                                                           int select_largest, int KR, float* __restrict__ fin,
+                                                           int* __restrict__ fin_cnt, int* __restrict__ status, NmsScratch g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+  float4* s_kbox = reinterpret_cast<float4*>(smem + KEEP * 8);
+  int* s_keep = reinterpret_cast<int*>(smem + KEEP * 8 + KEEP * 16);
+  float4* s_cbox = reinterpret_cast<float4*>(smem + KEEP * 28);
+  int* s_alive = reinterpret_cast<int*>(smem + KEEP * 28 + 256 * 16);
+  float4* s_reg = reinterpret_cast<float4*>(smem + KEEP * 28 + 256 * 20);  // KEEP * 16: boxes after bbreg
+  const int img = blockIdx.x;
+  const int n0 = row3_cnt[img];
+  const Row* r = rows3 + (size_t)img * KR;
+  const float* oo = oout + (size_t)img * KR * 15;
+  float* fo = fin + (size_t)img * KR * 15;
+  const size_t gb = (size_t)img * g.stride;
+  if (n0 <= KEEP) stage3_post_body<false>(r, oo, n0, thr_score, thr_nms, select_largest, keys, s_kbox, s_keep, s_reg, s_cbox, s_alive, fo, fin_cnt + img, status);
+  else stage3_post_body<true>(r, oo, n0, thr_score, thr_nms, select_largest, g.keys + gb, g.kbox + gb, g.keep + gb, g.reg + gb, s_cbox, s_alive, fo, fin_cnt + img, status);
 }
 
 // =============================================================================================
@@ -1437,7 +1494,10 @@ struct Mtcnn : HandleBase {
   PNetW pw; RNetW rw; ONetW ow;
   LevelTable cap_table;  // geometry at (max_height, max_width): sizes the buffers
   float *lvl = nullptr, *p1 = nullptr, *c2 = nullptr;
-  Cand *cand = nullptr, *keep1 = nullptr;
+  Cand* cand = nullptr;                       // stage-1 records, dense by cell: [frame][cap_out]
+  int *cells = nullptr, *keep1c = nullptr;    // per (level, frame) compact cell lists: P-Net hits / per-scale NMS survivors
+  int keep = KEEP;                            // rows per frame of the stage-2 / stage-3 tables (vnf_mtcnn_cfg.max_candidates)
+  NmsScratch scratch{};                       // global-memory fallback of the NMS kernels
   int *cand_cnt = nullptr, *keep1_cnt = nullptr, *row_cnt = nullptr, *row3_cnt = nullptr, *fin_cnt = nullptr, *status = nullptr;
   Row *rows = nullptr, *rows3 = nullptr;
   float *crops = nullptr, *rout = nullptr, *oout = nullptr, *fin = nullptr;
@@ -1445,7 +1505,6 @@ struct Mtcnn : HandleBase {
   Encoder *renc = nullptr, *oenc = nullptr;  // R-Net / O-Net plans on the exact-f32 MFMA core (candidates = batch)
   int* row_order = nullptr;                   // pyramid dispatch order (device), rebuilt when the frame size changes
   int row_order_h = 0, row_order_w = 0, row_order_cap = 0;
-  int cap_scale = CAP_SCALE;                  // stage-1 candidates per (level, frame): 4096 or 8192 (see vnf_mtcnn_create)
   int pnet1_lds = 0;                          // dynamic LDS granted to pnet_conv1_pool_mfma_kernel
   bool front = false;                         // conv1 + PReLU + pool1 of both nets by net_front_kernel (plans start at conv2)
   FrontW rfw{}, ofw{};
@@ -1469,19 +1528,19 @@ struct Mtcnn : HandleBase {
 
 // counts block (row_cnt .. status) followed by [B][FIN_FAST][15] result rows
 __global__ void pack_results_kernel(const int* __restrict__ cnt_block, int ncnt, const float* __restrict__ fin,
-                                    const int* __restrict__ fin_cnt, int B, float* __restrict__ stage) {
+                                    const int* __restrict__ fin_cnt, int B, int KR, float* __restrict__ stage) {
   int* so = reinterpret_cast<int*>(stage);
   for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < ncnt; i += gridDim.x * blockDim.x) so[i] = cnt_block[i];
   float* ro = stage + ncnt;
   const int total = B * FIN_FAST * 15;
   for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < total; i += gridDim.x * blockDim.x) {
     const int img = i / (FIN_FAST * 15), r = i - img * FIN_FAST * 15, k = r / 15;
-    ro[i] = k < fin_cnt[img] ? fin[(size_t)img * KEEP * 15 + r] : 0.f;
+    ro[i] = k < fin_cnt[img] ? fin[(size_t)img * KR * 15 + r] : 0.f;
   }
 }
 
 // device-resident copy of the last detection, frames concatenated in order (the host arrays' layout)
-__global__ void results_device_kernel(const float* __restrict__ fin, const int* __restrict__ fin_cnt, int max_out,
+__global__ void results_device_kernel(const float* __restrict__ fin, const int* __restrict__ fin_cnt, int max_out, int KR,
                                       int32_t* __restrict__ fidx, float* __restrict__ boxes, float* __restrict__ probs,
                                       float* __restrict__ points) {
   const int img = blockIdx.x;
@@ -1491,7 +1550,7 @@ __global__ void results_device_kernel(const float* __restrict__ fin, const int* 
   for (int k = threadIdx.x; k < c; k += blockDim.x) {
     const int o = off + k;
     if (o >= max_out) break;
-    const float* f = fin + ((size_t)img * KEEP + k) * 15;
+    const float* f = fin + ((size_t)img * KR + k) * 15;
     if (fidx) fidx[o] = img;
     if (boxes) { boxes[o * 4] = f[0]; boxes[o * 4 + 1] = f[1]; boxes[o * 4 + 2] = f[2]; boxes[o * 4 + 3] = f[3]; }
     if (probs) probs[o] = f[4];
@@ -1655,29 +1714,35 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
     m->p1 = (float*)m->dalloc(m->cap_p1 * 10 * B * 4);
     m->c2 = (float*)m->dalloc(m->cap_c2 * 16 * B * 4);
     const size_t nseg = (size_t)MAX_LEVELS * B;
-    {
-      // per-(level, frame) capacity of the stage-1 candidate table: 8192 when the 13-bit slot leaves room for every
-      // level's cell index (cells < 2^19: up to ~2.5 Mpx at min_face_size 12, 1080p at any), else 4096;
-      // cfg.max_candidates in (0, 4096] keeps the smaller table
-      long long max_cells = 0;
-      for (int l = 0; l < m->cap_table.n; ++l) max_cells = std::max(max_cells, (long long)m->cap_table.l[l].oh * m->cap_table.l[l].ow);
-      const bool want_small = cfg->max_candidates > 0 && cfg->max_candidates <= CAP_SCALE;
-      m->cap_scale = (!want_small && max_cells * 1.1 < (double)(1 << 19)) ? CAP_SCALE_MAX : CAP_SCALE;
-    }
-    m->cand = (Cand*)m->dalloc(nseg * m->cap_scale * sizeof(Cand));
-    m->keep1 = (Cand*)m->dalloc(nseg * KEEP * sizeof(Cand));
+    // rows per frame of the stage-2 / stage-3 tables: run-time (max_candidates), at least the LDS fast-path size
+    m->keep = std::max(KEEP, cfg->max_candidates);
+    if (!m->renc && m->keep != KEEP) { delete m; return fail(VNF_E_INVALID, "mtcnn: the LDS-resident nets (VNF_MTCNN_LDSNETS) keep the 2048-row tables"); }
+    const size_t KR = (size_t)m->keep;
+    m->cand = (Cand*)m->dalloc((size_t)B * m->cap_out * sizeof(Cand));
+    m->cells = (int*)m->dalloc((size_t)B * m->cap_out * 4);
+    m->keep1c = (int*)m->dalloc((size_t)B * m->cap_out * 4);
     m->cand_cnt = (int*)m->dalloc((nseg * 2 + (size_t)B * 3 + 16) * 4);
     m->keep1_cnt = m->cand_cnt + nseg;
     m->row_cnt = m->keep1_cnt + nseg;
     m->row3_cnt = m->row_cnt + B;
     m->fin_cnt = m->row3_cnt + B;
     m->status = m->fin_cnt + B;
-    m->rows = (Row*)m->dalloc((size_t)B * KEEP * sizeof(Row));
-    m->rows3 = (Row*)m->dalloc((size_t)B * KEEP * sizeof(Row));
-    m->crops = (float*)m->dalloc((size_t)B * KEEP * 3 * 48 * 48 * 4);
-    m->rout = (float*)m->dalloc((size_t)B * KEEP * 5 * 4);
-    m->oout = (float*)m->dalloc((size_t)B * KEEP * 15 * 4);
-    m->fin = (float*)m->dalloc((size_t)B * KEEP * 15 * 4);
+    m->rows = (Row*)m->dalloc((size_t)B * KR * sizeof(Row));
+    m->rows3 = (Row*)m->dalloc((size_t)B * KR * sizeof(Row));
+    m->crops = m->renc ? (float*)m->dalloc(16) : (float*)m->dalloc((size_t)B * KEEP * 3 * 48 * 48 * 4);   // planar crops: LDS-resident nets only
+    m->rout = (float*)m->dalloc((size_t)B * KR * 5 * 4);
+    m->oout = (float*)m->dalloc((size_t)B * KR * 15 * 4);
+    m->fin = (float*)m->dalloc((size_t)B * KR * 15 * 4);
+    {
+      // NMS scratch in global memory (lists longer than the LDS tables): per frame max(cells of the pyramid, rows)
+      const size_t st = std::max(m->cap_out, KR);
+      m->scratch.stride = (int)st;
+      m->scratch.keys = (unsigned long long*)m->dalloc((size_t)B * st * 8);
+      m->scratch.kbox = (float4*)m->dalloc((size_t)B * st * 16);
+      m->scratch.keep = (int*)m->dalloc((size_t)B * st * 4);
+      m->scratch.reg = (float4*)m->dalloc((size_t)B * st * 16);
+      if (!m->scratch.keys || !m->scratch.kbox || !m->scratch.keep || !m->scratch.reg || !m->cells || !m->keep1c) { delete m; return VNF_E_HIP; }
+    }
     {
       const size_t sb = ((size_t)B * 3 + 16) * 4 + (size_t)B * FIN_FAST * 15 * 4;
       m->stage = (float*)m->dalloc(sb);
@@ -1686,7 +1751,7 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
       if (const char* ff = getenv("VNF_FIN_FAST")) m->fin_fast = std::max(0, std::min(FIN_FAST, atoi(ff)));
     }
     m->offs = (int*)m->dalloc((size_t)(B + 1) * 4);
-    if (!m->lvl || !m->p1 || !m->c2 || !m->cand || !m->keep1 || !m->cand_cnt || !m->rows || !m->rows3 || !m->crops ||
+    if (!m->lvl || !m->p1 || !m->c2 || !m->cand || !m->cand_cnt || !m->rows || !m->rows3 || !m->crops ||
         !m->rout || !m->oout || !m->fin || !m->pw.w1 || !m->ow.d63b) {
       delete m;
       return VNF_E_HIP;
@@ -1696,7 +1761,7 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
     {
       int lds_max = 0;
       VNF_HIP(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, m->device));
-      const int need_img = CAP_IMG * 8 + KEEP * 20 + 256 * 20, need_scale = CAP_SCALE_MAX * 8 + KEEP * 20 + 256 * 20;   // per function, not per handle: the larger table
+      const int need_img = CAP_LDS_KEYS * 8 + KEEP * 20 + 256 * 20, need_scale = need_img;
       const int need_post = KEEP * 44 + 256 * 20, need_r = (13552 + 3388 + 864) * 4, need_o = (16928 + 14112 + 6912 + 1152) * 4;
       (void)hipFuncSetAttribute((const void*)nms_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need_img);
       (void)hipFuncSetAttribute((const void*)net_front_kernel<24, 11, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
@@ -1756,9 +1821,6 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   if (t.n == 0) return VNF_OK;  // image smaller than one cell: no detections
   if ((size_t)t.tot_px > m->cap_px || (size_t)t.tot_p1 > m->cap_p1 || (size_t)t.tot_c2 > m->cap_c2 || (size_t)t.tot_out > m->cap_out)
     return fail(VNF_E_CAPACITY, "mtcnn: pyramid exceeds handle capacity");
-  for (int l = 0; l < t.n; ++l)
-    if ((long long)t.l[l].oh * t.l[l].ow >= (m->cap_scale > CAP_SCALE ? (1 << 19) : (1 << 20)))
-      return fail(VNF_E_CAPACITY, "mtcnn: level too large for the cell index of the sort key");
   const int B = b;
   const size_t nseg = (size_t)MAX_LEVELS * cfg.max_batch;
   VNF_HIP(hipMemsetAsync(m->cand_cnt, 0, (nseg * 2 + (size_t)cfg.max_batch * 3 + 16) * 4, s));
@@ -1807,15 +1869,15 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   mark("pnet_conv1_pool", fB * ((double)t.tot_px * 12 + (double)t.tot_p1 * 40));
   hipLaunchKernelGGL(pnet_conv2_kernel, dim3(B, (t.tot_c2 + 255) / 256), dim3(256), 0, s, m->p1, t, m->pw, m->c2);
   mark("pnet_conv2", fB * ((double)t.tot_p1 * 40 + (double)t.tot_c2 * 64));
+  const int KR = m->keep, cap_out = (int)m->cap_out;
   hipLaunchKernelGGL(pnet_conv3_heads_kernel, dim3((t.tot_out + 255) / 256, B), dim3(256), 0, s, m->c2, t, m->pw,
-                     cfg.thresholds[0], B, m->cap_scale, m->cand, m->cand_cnt, m->status, m->prob_dbg, m->reg_dbg);
+                     cfg.thresholds[0], B, cap_out, m->cand, m->cells, m->cand_cnt, m->prob_dbg, m->reg_dbg);
   mark("pnet_conv3_heads", fB * (double)t.tot_c2 * 64);
-  const size_t lds_scale = (size_t)m->cap_scale * 8 + KEEP * 20 + 256 * 20;
-  const size_t lds_img = (size_t)CAP_IMG * 8 + KEEP * 20 + 256 * 20;
-  hipLaunchKernelGGL(nms_scale_kernel, dim3(t.n, B), dim3(256), lds_scale, s, m->cand, m->cand_cnt, t, B, 0.5f, m->keep1,
-                     m->keep1_cnt, m->status, m->cap_scale);
-  hipLaunchKernelGGL(nms_image_kernel, dim3(B), dim3(256), lds_img, s, m->keep1, m->keep1_cnt, t, B, 0.7f, W, H, m->rows,
-                     m->row_cnt, m->status);
+  const size_t lds_nms = (size_t)CAP_LDS_KEYS * 8 + KEEP * 20 + 256 * 20;
+  hipLaunchKernelGGL(nms_scale_kernel, dim3(t.n, B), dim3(256), lds_nms, s, m->cand, m->cells, m->cand_cnt, t, B, cap_out, 0.5f,
+                     m->keep1c, m->keep1_cnt, m->status, m->scratch);
+  hipLaunchKernelGGL(nms_image_kernel, dim3(B), dim3(256), lds_nms, s, m->cand, m->keep1c, m->keep1_cnt, t, B, cap_out, 0.7f, W, H,
+                     KR, m->rows, m->row_cnt, m->status, m->scratch);
   VNF_HIP(hipGetLastError());
   mark("nms_stage1", 0);
   const int ncnt = cfg.max_batch * 3 + 16;
@@ -1825,7 +1887,8 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
     VNF_HIP(hipStreamSynchronize(s));
     const int st = h[cfg.max_batch * 3];
     if (st & (ST_OVER_SCALE | ST_OVER_IMG | ST_OVER_KEEP))
-      return fail(VNF_E_CAPACITY, "mtcnn: candidate table overflow (status " + std::to_string(st) + ")");
+      return fail(VNF_E_CAPACITY, "mtcnn: candidate table overflow (status " + std::to_string(st) + "): a frame has more than " +
+                                  std::to_string(m->keep) + " stage-1 survivors; raise vnf_mtcnn_cfg.max_candidates");
     return VNF_OK;
   };
   // ---- stages 2 and 3 as launch sequences sized by (largest per-frame candidate count, total candidates): every kernel
@@ -1836,9 +1899,9 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
   auto crop = [&](const Row* rws, const int* cntp, int maxc, int S, float* dst, const int* offs, int c0, int cap) {
     if (crop_fast)
       // S / 8 row groups per candidate: 8 output rows per workgroup = 4 waves x 2 rows (measured best of 2..8 groups)
-      hipLaunchKernelGGL(crop_resize_rows_kernel, dim3(maxc, B, S / 8), dim3(256), 0, s, frames, H, W, rws, cntp, S, dst, m->status, offs, c0, cap);
+      hipLaunchKernelGGL(crop_resize_rows_kernel, dim3(maxc, B, S / 8), dim3(256), 0, s, frames, H, W, rws, cntp, S, dst, m->status, offs, c0, cap, KR);
     else
-      hipLaunchKernelGGL(crop_resize_kernel, dim3(maxc, B), dim3(256), 0, s, frames, H, W, rws, cntp, S, dst, m->status, offs, c0, cap);
+      hipLaunchKernelGGL(crop_resize_kernel, dim3(maxc, B), dim3(256), 0, s, frames, H, W, rws, cntp, S, dst, m->status, offs, c0, cap, KR);
   };
   // nets on the MFMA core: candidates of all frames form one dense batch, processed in chunks of `cap`
   auto run_net = [&](Encoder* enc, int cap, const Row* rws, const int* cntp, int maxc, int total, int S, int hw, float* dst,
@@ -1868,7 +1931,7 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
       if (!rep.empty()) fprintf(stderr, "%s n=%d\n%s", S == 24 ? "rnet" : "onet", n, rep.c_str());
       mark(S == 24 ? "rnet" : "onet", 0);
       hipLaunchKernelGGL(heads_scatter_kernel, dim3((maxc + 63) / 64, B), dim3(64), 0, s, (const float*)enc->bufs.back().ptr, hw,
-                         m->offs, cntp, c0, n, dst, nf, enc->dtype == F16X2 ? 1 : 0);
+                         m->offs, cntp, c0, n, dst, nf, enc->dtype == F16X2 ? 1 : 0, KR);
     }
     return VNF_OK;
   };
@@ -1882,7 +1945,7 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
       hipLaunchKernelGGL(rnet_kernel, dim3(max2, B), dim3(256), (13552 + 3388 + 864) * 4, s, m->crops, m->row_cnt, m->rw, m->rout);
     }
     hipLaunchKernelGGL(stage2_post_kernel, dim3(B), dim3(256), lds_post, s, m->rows, m->row_cnt, m->rout, cfg.thresholds[1], 0.7f,
-                       W, H, m->rows3, m->row3_cnt, m->status);
+                       W, H, KR, m->rows3, m->row3_cnt, m->status, m->scratch);
     VNF_HIP(hipGetLastError());
     mark("stage2_post", 0);
     return VNF_OK;
@@ -1896,9 +1959,9 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
       hipLaunchKernelGGL(onet_kernel, dim3(max3, B), dim3(512), (16928 + 14112 + 6912 + 1152) * 4, s, m->crops, m->row3_cnt, m->ow, m->oout);
     }
     hipLaunchKernelGGL(stage3_post_kernel, dim3(B), dim3(256), lds_post, s, m->rows3, m->row3_cnt, m->oout, cfg.thresholds[2], 0.7f,
-                       cfg.select_largest, m->fin, m->fin_cnt, m->status);
+                       cfg.select_largest, KR, m->fin, m->fin_cnt, m->status, m->scratch);
     m->last_b = B;
-    hipLaunchKernelGGL(pack_results_kernel, dim3(B), dim3(256), 0, s, m->row_cnt, ncnt, m->fin, m->fin_cnt, B, m->stage);
+    hipLaunchKernelGGL(pack_results_kernel, dim3(B), dim3(256), 0, s, m->row_cnt, ncnt, m->fin, m->fin_cnt, B, KR, m->stage);
     VNF_HIP(hipGetLastError());
     mark("stage3_post", 0);
     return VNF_OK;
@@ -1909,7 +1972,8 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
     mark("readback", 0);
     const int st = h[cfg.max_batch * 3];
     if (st & (ST_OVER_SCALE | ST_OVER_IMG | ST_OVER_KEEP))
-      return fail(VNF_E_CAPACITY, "mtcnn: candidate table overflow (status " + std::to_string(st) + ")");
+      return fail(VNF_E_CAPACITY, "mtcnn: candidate table overflow (status " + std::to_string(st) + "): a frame has more than " +
+                                  std::to_string(m->keep) + " stage-1 survivors; raise vnf_mtcnn_cfg.max_candidates");
     return VNF_OK;
   };
   auto counts_of = [&](int base, int& mx, int& tot) {
@@ -1951,7 +2015,7 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
       if (r == VNF_OK) r = stage3(mx2, tot2);      // stage-3 rows are a subset of stage-2 rows: exact upper bounds
     } else {
       m->last_b = B;
-      hipLaunchKernelGGL(pack_results_kernel, dim3(B), dim3(256), 0, s, m->row_cnt, ncnt, m->fin, m->fin_cnt, B, m->stage);
+      hipLaunchKernelGGL(pack_results_kernel, dim3(B), dim3(256), 0, s, m->row_cnt, ncnt, m->fin, m->fin_cnt, B, KR, m->stage);
     }
     if (r == VNF_OK) r = readback();
     if (r != VNF_OK) return r;
@@ -1961,8 +2025,8 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
     counts_of(0, mx2, tot2);
     counts_of(cfg.max_batch, mx3, tot3);
     sp.valid = true; sp.b = B; sp.H = H; sp.W = W;
-    sp.max2 = padded(mx2, KEEP); sp.total2 = padded(tot2, B * KEEP);
-    sp.max3 = padded(mx3, KEEP); sp.total3 = padded(tot3, B * KEEP);
+    sp.max2 = padded(mx2, KR); sp.total2 = padded(tot2, B * KR);
+    sp.max3 = padded(mx3, KR); sp.total3 = padded(tot3, B * KR);
   }
   int maxf = 0;
   for (int i = 0; i < B; ++i) { cnt[i] = h[2 * cfg.max_batch + i]; maxf = std::max(maxf, cnt[i]); }
@@ -1974,7 +2038,7 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
       memcpy(&fin[(size_t)i * maxf * 15], rows + (size_t)i * FIN_FAST * 15, (size_t)maxf * 15 * 4);
     return VNF_OK;
   }
-  VNF_HIP(hipMemcpy2DAsync(fin.data(), (size_t)maxf * 15 * 4, m->fin, (size_t)KEEP * 15 * 4, (size_t)maxf * 15 * 4, B,
+  VNF_HIP(hipMemcpy2DAsync(fin.data(), (size_t)maxf * 15 * 4, m->fin, (size_t)KR * 15 * 4, (size_t)maxf * 15 * 4, B,
                            hipMemcpyDeviceToHost, s));
   VNF_HIP(hipStreamSynchronize(s));
   return VNF_OK;
@@ -2047,7 +2111,7 @@ extern "C" int vnf_mtcnn_results_device(vnf_handle h, int32_t* frame_idx, float*
   Mtcnn* m = static_cast<Mtcnn*>(hb);
   if (max_out < 0) return fail(VNF_E_INVALID, "vnf_mtcnn_results_device: bad argument");
   if (m->last_b == 0 || max_out == 0) return VNF_OK;  // the last detection found nothing
-  hipLaunchKernelGGL(results_device_kernel, dim3(m->last_b), dim3(64), 0, (hipStream_t)stream, m->fin, m->fin_cnt, max_out,
+  hipLaunchKernelGGL(results_device_kernel, dim3(m->last_b), dim3(64), 0, (hipStream_t)stream, m->fin, m->fin_cnt, max_out, m->keep,
                      frame_idx, boxes, probs, points);
   VNF_HIP(hipGetLastError());
   return VNF_OK;
@@ -2062,8 +2126,9 @@ extern "C" int vnf_mtcnn_debug_stage3(vnf_handle h, const float* boxes, const fl
   try {
     HandleBase* hb = reinterpret_cast<HandleBase*>(h);
     if (!hb || hb->kind != 3) return fail(VNF_E_INVALID, "not an MTCNN handle");
-    if (!boxes || !onet_out || n < 0 || n > KEEP || !fin_out || !n_out) return fail(VNF_E_INVALID, "vnf_mtcnn_debug_stage3: bad argument");
+    if (!boxes || !onet_out || n < 0 || !fin_out || !n_out) return fail(VNF_E_INVALID, "vnf_mtcnn_debug_stage3: bad argument");
     Mtcnn* m = static_cast<Mtcnn*>(hb);
+    if (n > m->keep) return fail(VNF_E_CAPACITY, "vnf_mtcnn_debug_stage3: more rows than the handle's tables hold");
     hipStream_t s = (hipStream_t)stream;
     std::vector<Row> rows((size_t)std::max(n, 1));
     for (int i = 0; i < n; ++i) {
@@ -2077,7 +2142,7 @@ extern "C" int vnf_mtcnn_debug_stage3(vnf_handle h, const float* boxes, const fl
     VNF_HIP(hipMemsetAsync(m->status, 0, 4, s));
     const size_t lds_post = (size_t)KEEP * 28 + 256 * 20 + KEEP * 16;
     hipLaunchKernelGGL(stage3_post_kernel, dim3(1), dim3(256), lds_post, s, m->rows3, m->row3_cnt, m->oout, m->cfg.thresholds[2],
-                       0.7f, m->cfg.select_largest, m->fin, m->fin_cnt, m->status);
+                       0.7f, m->cfg.select_largest, m->keep, m->fin, m->fin_cnt, m->status, m->scratch);
     VNF_HIP(hipGetLastError());
     int nk = 0;
     VNF_HIP(hipMemcpyAsync(&nk, m->fin_cnt, 4, hipMemcpyDeviceToHost, s));

@@ -42,7 +42,7 @@ class MTCNN:
         self.training = False
         self._sd = state_dicts or tuple(_load_net(n) for n in ("pnet", "rnet", "onet"))
         self._cap = [int(max_batch), int(max_height), int(max_width)]
-        self._max_candidates = int(max_candidates)    # vnf_mtcnn_cfg.max_candidates (0: the library's default table size)
+        self._max_candidates = int(max_candidates)    # vnf_mtcnn_cfg.max_candidates: rows per frame of the stage tables (0: 2048); grows on overflow
         self._handle = None
         self._handle_key = None
         self._frames = None
@@ -142,6 +142,13 @@ class MTCNN:
                                           ctypes.byref(n_out), _lib.current_stream_ptr())
             if rc == -4 and n_out.value > cap:
                 cap = int(n_out.value)
+                continue
+            if rc == -4 and b"candidate table overflow" in lib.vnf_last_error() and self._max_candidates < (1 << 20):
+                # a frame with more stage-1 survivors than the stage tables have rows (the reference has no cap,
+                # detect_face.py:79-93): grow the tables and run the batch again -- like a vector, never a truncation
+                self._max_candidates = max(4096, 2 * max(self._max_candidates, 2048))
+                self._handle_key = None
+                hd = self._ensure(b, h, w)
                 continue
             _lib.check(rc)
             n = n_out.value
