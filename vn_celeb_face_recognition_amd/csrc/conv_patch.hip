@@ -246,6 +246,8 @@ static const PatchCfg kPatch[] = {
     {64, 128, 2, 2, 4},
     // deeper weight rings: the patch is resident, so ring stages are only BN x 128 B and more of them keep more bytes in flight
     {256, 64, 4, 2, 6},  {128, 64, 4, 2, 6},  {256, 128, 4, 2, 4}, {256, 32, 8, 1, 6},
+    // <= 80 KiB of LDS: two workgroups per CU, so one's patch load / epilogue runs under the other's K loop
+    {128, 96, 4, 1, 3},  {128, 96, 2, 2, 3},  {64, 192, 1, 4, 3},
 };
 constexpr int kNumPatch = (int)(sizeof(kPatch) / sizeof(kPatch[0]));
 
@@ -344,6 +346,9 @@ static hipError_t launch_patch_typed(int pcfg, const KArgs& k, int lds, hipStrea
     case 17: return launch_one<T, 128, 64, 4, 2, 6>(k, lds, s);
     case 18: return launch_one<T, 256, 128, 4, 2, 4>(k, lds, s);
     case 19: return launch_one<T, 256, 32, 8, 1, 6>(k, lds, s);
+    case 20: return launch_one<T, 128, 96, 4, 1, 3>(k, lds, s);
+    case 21: return launch_one<T, 128, 96, 2, 2, 3>(k, lds, s);
+    case 22: return launch_one<T, 64, 192, 1, 4, 3>(k, lds, s);
   }
   return hipErrorInvalidValue;
 }
