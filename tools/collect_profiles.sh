@@ -9,6 +9,7 @@ mkdir -p $OUT
 export VNF_TUNE_CACHE=$OUT/tune_cache.txt
 cd $ROOT
 STEPS=6
+if [ -z "$SKIP_EARLY" ]; then   # SKIP_EARLY=1: resume after the bf16 counter / trace passes
 # 0. tune cache + the plan listing that keys the kernel trace by layer
 VNF_PRINT_PLAN=1 python tools/pmc_one_step.py 256 3 > $OUT/plan.txt 2>/dev/null || exit 1
 cd /tmp && export TMPDIR=/tmp
@@ -22,6 +23,8 @@ cd $ROOT
 python tools/traffic_from_pmc.py $OUT/pmc_f/f_counter_collection.csv $OUT/pmc_w/w_counter_collection.csv 7 $OUT/${R}_traffic.json > /dev/null || exit 1
 python tools/mfma_busy_from_pmc.py $OUT/pmc_m/m_counter_collection.csv $OUT/pmc_m/m_kernel_trace.csv > $OUT/${R}_mfma_busy_bs256_bf16.txt || exit 1
 python tools/layer_trace.py $OUT/plan.txt $OUT/kt_layers/l_kernel_trace.csv $STEPS 3 > $OUT/${R}_irv1_bs256_bf16_3lane_layer_trace.txt || exit 1
+fi
+cd $ROOT
 # 2b. the same per-layer table for the in-gate dtype (f16x2: planar split-f16, fused stem / Block35 / Block17 kernels)
 VNF_PRINT_PLAN=1 python tools/pmc_one_step.py 256 3 f16x2 > $OUT/plan_f16x2.txt 2>/dev/null || exit 1
 ( cd /tmp && rocprofv3 --kernel-trace -d $OUT/kt_layers_x -o l --output-format csv -- python3 $ROOT/tools/pmc_one_step.py 256 $STEPS f16x2 > $OUT/kt_layers_x.log 2>&1 ) || exit 1

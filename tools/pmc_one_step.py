@@ -27,7 +27,9 @@ if os.environ.get("VNF_PRINT_PLAN"):
         if label.startswith("conv2d_4b"):
             # the ops up to here form the stem group, which the engine runs once per sub-batch (engine.cpp groups:
             # 128 images unfused, the whole batch when conv2d_2a/2b/maxpool are fused)
-            chunk = int(os.environ.get("VNF_STEM_CHUNK", "256" if DT in ("bf16", "f16") and (int(os.environ.get("VNF_FUSE", "7")) & 4) else "128"))
+            fuse = int(os.environ.get("VNF_FUSE", "15"))
+            fused_stem = (DT in ("bf16", "f16") and (fuse & 4)) or (DT == "f16x2" and (fuse & 12) == 12)
+            chunk = int(os.environ.get("VNF_STEM_CHUNK", "256" if fused_stem else "128"))
             print("GROUP_END %d" % ((bs + chunk - 1) // chunk), flush=True)
     torch.cuda.synchronize()
     print("PLAN_END", flush=True)
