@@ -99,26 +99,13 @@ __global__ void __launch_bounds__(256) stem_conv1a_kernel(const TI* __restrict__
   const unsigned img = i / (SO * SO), p = i - img * (SO * SO);
   const int oy = (int)(p / SO), ox = (int)(p - (unsigned)oy * SO);
   const TI* src = x + (size_t)img * 3 * S * S + (size_t)(2 * oy) * S + 2 * ox;
-  // the three taps of a filter row are columns 2ox .. 2ox+2: ONE 8-byte (16-bit inputs) / 16-byte (fp32 inputs) load of
-  // columns 2ox .. 2ox+3 per (channel, filter row) instead of three scalar loads -- 9 loads per pixel, not 27 (the row has
-  // 160 columns, so column 2*78+3 = 159 is still inside it)
   float in[27];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const TI* rp = src + (size_t)c * S * S + kh * S;
-      if constexpr (sizeof(TI) == 2) {
-        typedef TI t4 __attribute__((ext_vector_type(4)));
-        const t4 v = *reinterpret_cast<const t4*>(rp);   // dword-aligned (2*ox columns of 2 bytes): fine for global loads
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) in[(c * 3 + kh) * 3 + kw] = (float)v[kw];
-      } else {
-        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(rp);
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) in[(c * 3 + kh) * 3 + kw] = v[kw];
-      }
-    }
+      for (int kw = 0; kw < 3; ++kw) in[(c * 3 + kh) * 3 + kw] = to_f(src[(size_t)c * S * S + kh * S + kw]);
   f2_t acc[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc[j] = f2_t{wt[27 * 32 + 2 * j], wt[27 * 32 + 2 * j + 1]};

@@ -20,6 +20,7 @@ struct KArgs {  // device-side copy of ConvArgs (POD)
   const char* zero;  // >= 16 zero bytes
   int ldx, H, W, Ho, Wo, sh, sw, ph, pw;
   int K, Kpad, nkt;
+  int wrs, wts;  // weight image strides in bytes: between output channels, between K tiles
   int ncls, cout_pad;
   int M, Cout, tiles_n, nblk;
   int ldres, act, out_f32;
@@ -29,6 +30,7 @@ struct KArgs {  // device-side copy of ConvArgs (POD)
   // patch kernel (conv_patch.hip) geometry: taps, channels per tap, LDS pixel pitch in 16-byte
   // slots, padded row width, virtual (vertically padded) image height, patch bytes
   int KH, KW, Cin, pp, Wp, Hv, patch_bytes;
+  int lds_bytes;  // patch kernel: dynamic LDS of the launch (what the epilogue may stage into)
   long long* dbg;  // in-kernel stamp buffer of the instrumented build (tools), else null
 };
 
@@ -190,10 +192,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-// ---- epilogue shared by both kernels: fp32 accumulators -> LDS -> whole NHWC rows ------------
+// ---- epilogue shared by the conv kernels: fp32 accumulators -> LDS -> whole NHWC rows ------------
+// Fast form (the stem / reduction convolutions of the 2-byte plans: bias + ReLU only, no residual, no border-class bias,
+// output in T): bias and activation are applied in the accumulator layout, the tile is staged ALREADY ROUNDED to T --
+// half the LDS bytes, so the whole tile fits one pass and one barrier -- and every global load (the bias) is issued
+// before the first store: vmcnt counts loads and stores together in issue order, so a load behind a store waits for
+// the store's acknowledgement (the staged fp32 form paid that once per pass: conv2d_4a's epilogue was 17 k of its
+// workgroups' 59 k cycles, in-kernel stamps).  Same fp32 sum, bias add, max and rounding as the general form, so the
+// results are bit-identical to it.
+template <typename T, int BM, int BN>
+__device__ __forceinline__ bool conv_epilogue_is_fast(const KArgs& a, int avail) {
+  if constexpr (sizeof(T) != 2)
+    return false;
+  else
+    return !a.res && a.ncls == 1 && !a.out_f32 && a.act != ACT_PRELU && BM * (BN * 2 + 16) <= avail;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int LDS_BYTES>
 __device__ __forceinline__ void conv_epilogue(const KArgs& a, f32x4_t (&acc)[BM / WM / 16][BN / WN / 16], char* smem,
-                                              int m0, int n0) {
+                                              int m0, int n0, int avail = LDS_BYTES) {
   static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "wave tiles are whole 16x16 MFMA tiles");
   constexpr int ES = (int)sizeof(T);
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
@@ -201,6 +218,47 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, f32x4_t (&acc)[BM 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, frow = lane & 15, fgrp = lane >> 4;
   const int HoWo = a.Ho * a.Wo;
+  if constexpr (sizeof(T) == 2) {
+    if (conv_epilogue_is_fast<T, BM, BN>(a, avail)) {
+      constexpr int PITCH = BN * 2 + 16;  // +16 B: the 16 rows of one ds_write_b64 land on different banks
+      typedef T tx4 __attribute__((ext_vector_type(4)));
+      f32x4_t bias[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int c = n0 + wn * WTN + j * 16 + fgrp * 4;
+        bias[j] = c < a.Cout ? *reinterpret_cast<const f32x4_t*>(a.bias + c) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+      const bool relu = a.act == ACT_RELU;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          tx4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][j][e] + bias[j][e];
+            if (relu) v = fmaxf(v, 0.f);
+            o[e] = (T)v;
+          }
+          *reinterpret_cast<tx4*>(smem + (wm * WTM + i * 16 + frow) * PITCH + (wn * WTN + j * 16 + fgrp * 4) * 2) = o;
+        }
+      __syncthreads();
+      constexpr int CPR8 = BN / 8;
+      for (int idx = tid; idx < BM * CPR8; idx += NT) {
+        const int r = idx / CPR8, cc = idx - r * CPR8;
+        const int m = m0 + r, c = n0 + cc * 8;
+        if (m < a.M && c < a.Cout) {
+          int sg = 0;
+#pragma unroll
+          for (int s = 1; s < 4; ++s)
+            if (s < a.nseg && c >= a.seg_c0[s]) sg = s;
+          *reinterpret_cast<uint4*>(a.seg_ptr[sg] + ((size_t)m * a.seg_ld[sg] + (c - a.seg_c0[sg])) * 2) =
+              *reinterpret_cast<const uint4*>(smem + r * PITCH + cc * 16);
+        }
+      }
+      return;
+    }
+  }
   float* sC = reinterpret_cast<float*>(smem);
   constexpr int CST = BN + 4;  // floats per staged row (+16 B pad: conflict-free float4 writes)
   constexpr int CPR = BN / 8;  // 8-channel chunks per row

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const KArgs
   const int lchunk = lcol ^ (lrow & 7);  // logical k-chunk this lane fetches (physical slot = lcol)
   int abase[AP], ahi[AP], awi[AP];
   row_setup<AP, RS>(a, m0, lrow, abase, ahi, awi);
-  const char* wsrc = a.w + ((size_t)(n0 + lrow) * a.Kpad + lchunk * CH) * ES;
+  const char* wsrc = a.w + (size_t)(n0 + lrow) * a.wrs + lchunk * 16;
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);  // LDS byte address of the ring
 
   f32x4_t acc[TM][TN];
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const KArgs
     }
 #pragma unroll
     for (int p = 0; p < BP; ++p)
-      glds16(wsrc + ((size_t)(RS * p) * a.Kpad + (size_t)kt * BKE) * ES, sbase + BM * 128 + p * (NW * 1024));
+      glds16(wsrc + (size_t)(RS * p) * a.wrs + (size_t)kt * a.wts, sbase + BM * 128 + p * (NW * 1024));
     g_c += BKE;
     g_norm();
   };
@@ -516,11 +516,12 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t s) {
   k.ldx = a.ldx; k.H = a.H; k.W = a.W; k.Ho = a.Ho; k.Wo = a.Wo;
   k.sh = a.sh; k.sw = a.sw; k.ph = a.ph; k.pw = a.pw;
   k.K = a.K; k.Kpad = a.Kpad; k.nkt = a.Kpad / bke;
+  k.wrs = a.Kpad * es; k.wts = 128;
   k.ncls = a.ncls; k.cout_pad = a.cout_pad;
   k.M = a.M; k.Cout = a.Cout; k.tiles_n = 0; k.nblk = 0;
   k.ldres = a.ldres; k.act = a.act; k.out_f32 = a.out_f32;
   k.nseg = a.nseg;
-  k.KH = a.KH; k.KW = a.KW; k.Cin = a.Cin; k.pp = k.Wp = k.Hv = k.patch_bytes = 0; k.dbg = nullptr;
+  k.KH = a.KH; k.KW = a.KW; k.Cin = a.Cin; k.pp = k.Wp = k.Hv = k.patch_bytes = k.lds_bytes = 0; k.dbg = nullptr;
   for (int i = 0; i < 4; ++i) {
     k.seg_c0[i] = i < a.nseg ? a.seg[i].c0 : 1 << 30;
     k.seg_c1[i] = i < a.nseg ? a.seg[i].c1 : 1 << 30;

@@ -18,6 +18,8 @@
 //   patch + ((vb(p)-v0 + kh)*Wp + ox(p) + kw)*PP*16 + cc*16  =  pb[p] + ptab[k-chunk]
 // -- one add per fragment read, the table is built from the layer's ktab.  K tiles, MFMA operand
 // roles and the epilogue are those of conv_igemm.hip, so results are bit-identical to it.
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -27,7 +29,7 @@
 
 namespace vnf {
 
-template <typename T, int BM, int BN, int WM, int WN, int S>
+template <typename T, int BM, int BN, int WM, int WN, int S, bool DBG = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv_patch_kernel(const KArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = (int)sizeof(T);
@@ -41,6 +43,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_patch_kernel(const KArgs a) 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // instrumented build (tools/stamp_patch.py): cycle stamps of workgroup 700, 40 per wave
+  int nstamp = 0;
+  auto stamp = [&]() {
+    if constexpr (DBG) {
+      if (a.dbg && blockIdx.x == 700 && lane == 0 && nstamp < 40) a.dbg[wave * 40 + nstamp] = __builtin_readcyclecounter();
+      ++nstamp;
+    }
+  };
+  stamp();
   const int wm = wave / WN, wn = wave % WN;
   const int bid = xcd_remap(blockIdx.x, a.nblk);
   const int tile_m = bid / a.tiles_n, tile_n = bid - tile_m * a.tiles_n;
@@ -66,12 +77,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_patch_kernel(const KArgs a) 
   const int npieces = (nslots + 63) >> 6;          // DMA pieces (1 KiB) per plane
   const int plane_bytes = npieces * 1024;
   // k-chunk -> byte offset inside the patch relative to the pixel's base (-1: K padding)
+  // (its first -- usually only -- round of global loads is issued up here and consumed after the DMA burst below)
+  const int4 e_first = tid < nkt * 8 ? a.ktab[tid] : int4{0, 0, 0, 0};
+  auto fill_table = [&]() {
   for (int i = tid; i < nkt * 8; i += NT) {
-    const int4 e = a.ktab[i];
+    const int4 e = i == tid ? e_first : a.ktab[i];
     const int cc = (e.x - (e.y * a.W + e.z) * a.ldx) / CH;   // 16-byte chunk inside the pixel (planar: 2 * unit + plane)
     const int slot = PL ? (cc >> 1) : cc, plane = PL ? (cc & 1) : 0;
     sP[i] = e.w ? ((e.y * a.Wp + e.z) * a.pp + slot) * 16 + plane * plane_bytes : -1;
   }
+  };
   if (tid < 4) reinterpret_cast<int*>(zslot)[tid] = 0;
 
   // the patch: one 1-KiB DMA piece per wave instruction, lane-linear in LDS
@@ -95,7 +110,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_patch_kernel(const KArgs a) 
 
   const int lrow = tid >> 3, lcol = tid & 7;
   const int lchunk = lcol ^ (lrow & 7);
-  const char* wsrc = a.w + ((size_t)(n0 + lrow) * a.Kpad + lchunk * CH) * ES;
+  const char* wsrc = a.w + (size_t)(n0 + lrow) * a.wrs + lchunk * 16;
   int np = 0;  // weight pieces this wave issues per K tile (wave-uniform)
 #pragma unroll
   for (int p = 0; p < BPM; ++p)
@@ -106,7 +121,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_patch_kernel(const KArgs a) 
 #pragma unroll
     for (int p = 0; p < BPM; ++p)
       if (RS * p + 8 * wave < BN)
-        glds16(wsrc + ((size_t)(RS * p) * a.Kpad + (size_t)kt * BKE) * ES, sbase + p * (NW * 1024));
+        glds16(wsrc + (size_t)(RS * p) * a.wrs + (size_t)kt * a.wts, sbase + p * (NW * 1024));
   };
   auto wait_ring = [&]() {  // all but the (S-2)*np youngest pieces of this wave have landed
     switch (np) {
@@ -125,6 +140,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_patch_kernel(const KArgs a) 
 #pragma unroll
   for (int t = 0; t < S - 1; ++t)
     if (t < nkt) issue(t);
+  fill_table();  // visible to every wave after the first K tile's barrier
+  stamp();
 
   f32x4_t acc[TM][TN];
 #pragma unroll
@@ -222,7 +239,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_patch_kernel(const KArgs a) 
   } else {
     bool pend = false;
     for (int kt = 0; kt < nkt; ++kt) {
+      stamp();
       sync_tile(kt);
+      stamp();
       read_frags(kt, 0, t0);
       if (pend) mma(1);
       pend = BKE / 2 < a.K - kt * BKE;
@@ -233,8 +252,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_patch_kernel(const KArgs a) 
     }
     if (pend) mma(1);
   }
+  stamp();
   __syncthreads();
-  conv_epilogue<T, BM, BN, WM, WN, EPI>(a, acc, smem, m0, n0);
+  stamp();
+  conv_epilogue<T, BM, BN, WM, WN, EPI>(a, acc, smem, m0, n0, a.lds_bytes);
+  stamp();
 }
 
 // ===================================================================== host side
@@ -248,6 +270,9 @@ static const PatchCfg kPatch[] = {
     {256, 64, 4, 2, 6},  {128, 64, 4, 2, 6},  {256, 128, 4, 2, 4}, {256, 32, 8, 1, 6},
     // <= 80 KiB of LDS: two workgroups per CU, so one's patch load / epilogue runs under the other's K loop
     {128, 96, 4, 1, 3},  {128, 96, 2, 2, 3},  {64, 192, 1, 4, 3},
+    // 192-row tiles: conv2d_4a's 331,776 pixels are 1296 tiles of 256 = 5.06 rounds over 256 CUs (a sixth round for 16
+    // workgroups), but 1728 tiles of 192 = 6.75 rounds of 3/4 the size
+    {192, 192, 4, 2, 3},
 };
 constexpr int kNumPatch = (int)(sizeof(kPatch) / sizeof(kPatch[0]));
 
@@ -349,8 +374,40 @@ static hipError_t launch_patch_typed(int pcfg, const KArgs& k, int lds, hipStrea
     case 20: return launch_one<T, 128, 96, 4, 1, 3>(k, lds, s);
     case 21: return launch_one<T, 128, 96, 2, 2, 3>(k, lds, s);
     case 22: return launch_one<T, 64, 192, 1, 4, 3>(k, lds, s);
+    case 23: return launch_one<T, 192, 192, 4, 2, 3>(k, lds, s);
   }
   return hipErrorInvalidValue;
+}
+
+// Instrumented launch (tools/stamp_patch.py): VNF_PATCH_STAMP=<file> dumps cycle stamps of workgroup 700 of every bf16
+// {256,192,4,2,3} launch with more than 700 workgroups: start, prologue issued, before / after the barrier of every K
+// tile, K loop done, epilogue barrier, end.
+static hipError_t launch_patch_stamped(const KArgs& k, int lds, hipStream_t s) {
+  static long long* dbuf = nullptr;
+  const int n = 8 * 40;
+  if (!dbuf && hipMalloc((void**)&dbuf, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+  (void)hipMemsetAsync(dbuf, 0, n * 8, s);
+  KArgs kk = k;
+  kk.dbg = dbuf;
+  kk.tiles_n = (k.Cout + 191) / 192;
+  kk.nblk = ((k.M + 255) / 256) * kk.tiles_n;
+  (void)hipFuncSetAttribute((const void*)conv_patch_kernel<__bf16, 256, 192, 4, 2, 3, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((conv_patch_kernel<__bf16, 256, 192, 4, 2, 3, true>), dim3(kk.nblk), dim3(512), lds, s, kk);
+  hipError_t e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return e;
+  static long long host[8 * 40];
+  (void)hipMemcpy(host, dbuf, n * 8, hipMemcpyDeviceToHost);
+  if (FILE* f = fopen(getenv("VNF_PATCH_STAMP"), "a")) {
+    fprintf(f, "launch M=%d N=%d nkt=%d nblk=%d\n", k.M, k.Cout, k.nkt, kk.nblk);
+    for (int w = 0; w < 8; ++w) {
+      fprintf(f, "%d", w);
+      for (int i = 0; i < 40; ++i) fprintf(f, " %lld", host[w * 40 + i] ? host[w * 40 + i] - host[0] : -1LL);
+      fprintf(f, "\n");
+    }
+    fclose(f);
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_patch(const ConvArgs& a, const KArgs& k, int pcfg, hipStream_t s) {
@@ -359,7 +416,9 @@ hipError_t launch_patch(const ConvArgs& a, const KArgs& k, int pcfg, hipStream_t
   patch_geom(a, kPatch[pcfg], g);
   KArgs kk = k;
   kk.KH = a.KH; kk.KW = a.KW; kk.Cin = a.Cin;
-  kk.pp = g.pp; kk.Wp = g.Wp; kk.Hv = g.Hv; kk.patch_bytes = g.patch_bytes;
+  kk.pp = g.pp; kk.Wp = g.Wp; kk.Hv = g.Hv; kk.patch_bytes = g.patch_bytes; kk.lds_bytes = g.lds;
+  if (getenv("VNF_PATCH_STAMP") && pcfg == 7 && a.dtype == BF16 && ((k.M + 255) / 256) * ((k.Cout + 191) / 192) > 700)
+    return launch_patch_stamped(kk, g.lds, s);
   switch (a.dtype) {
     case BF16: return launch_patch_typed<__bf16>(pcfg, kk, g.lds, s);
     case F16: return launch_patch_typed<_Float16>(pcfg, kk, g.lds, s);

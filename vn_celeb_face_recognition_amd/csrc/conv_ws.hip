@@ -71,7 +71,7 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_ws_kernel(const
         abase[p] = 0;
       }
     }
-    const char* wsrc = a.w + ((size_t)(n0 + lw * 8 + prow) * a.Kpad + lchunk * CH) * ES;
+    const char* wsrc = a.w + (size_t)(n0 + lw * 8 + prow) * a.wrs + lchunk * 16;
     const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
     auto issue = [&](int kt) {
       const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((kt % S) * STAGE) + (unsigned)(lw * 1024));
@@ -85,7 +85,7 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_ws_kernel(const
       }
 #pragma unroll
       for (int p = 0; p < LB; ++p)
-        glds16(wsrc + ((size_t)(p * LW * 8) * a.Kpad + (size_t)kt * BKE) * ES, sbase + BM * 128 + p * (LW * 1024));
+        glds16(wsrc + (size_t)(p * LW * 8) * a.wrs + (size_t)kt * a.wts, sbase + BM * 128 + p * (LW * 1024));
     };
 #pragma unroll
     for (int t = 0; t < S - 1; ++t)
@@ -113,7 +113,11 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_ws_kernel(const
       if (kt + S - 1 < nkt) issue(kt + S - 1);
     }
     __syncthreads();
-    for (int pass = 0; pass < EPASS; ++pass) {  // the consumers' epilogue barriers
+    if (conv_epilogue_is_fast<T, BM, BN>(a, S * STAGE)) {  // the consumers' epilogue barriers
+      __syncthreads();
+      return;
+    }
+    for (int pass = 0; pass < EPASS; ++pass) {
       __syncthreads();
       __syncthreads();
     }
@@ -214,7 +218,7 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_ws_kernel(const
       }
     }
     __syncthreads();
-    conv_epilogue<T, BM, BN, WM, WN, EPI_LDS>(a, acc, smem, m0, n0);
+    conv_epilogue<T, BM, BN, WM, WN, EPI_LDS>(a, acc, smem, m0, n0, S * STAGE);
     return;
   }
   bool pend = false;
@@ -253,7 +257,7 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_ws_kernel(const
   }
   if (pend) mma(1);
   __syncthreads();
-  conv_epilogue<T, BM, BN, WM, WN, EPI_LDS>(a, acc, smem, m0, n0);
+  conv_epilogue<T, BM, BN, WM, WN, EPI_LDS>(a, acc, smem, m0, n0, S * STAGE);
 }
 
 // ===================================================================== host side
@@ -262,6 +266,9 @@ static const WsCfg kWs[] = {
     {256, 128, 2, 2, 3, 4}, {256, 128, 4, 1, 3, 4}, {128, 128, 2, 2, 3, 4}, {128, 128, 2, 2, 4, 4},
     {256, 64, 4, 1, 3, 4},  {128, 192, 2, 2, 3, 4}, {128, 256, 2, 2, 3, 4}, {128, 64, 2, 2, 4, 4},
     {256, 128, 2, 2, 3, 2}, {128, 128, 2, 2, 4, 2}, {128, 192, 2, 2, 3, 2}, {192, 128, 2, 2, 3, 4},
+    // 160-row tiles: the 17x17 layers' 73,984 pixels are 578 tiles of 128 = 2.26 rounds over 256 CUs (a third round for a
+    // quarter of them) but 463 tiles of 160 = 1.81
+    {160, 256, 2, 2, 3, 4}, {160, 192, 2, 2, 3, 4},
 };
 constexpr int kNumWs = (int)(sizeof(kWs) / sizeof(kWs[0]));
 
@@ -311,6 +318,8 @@ static hipError_t launch_ws_typed(int wcfg, const KArgs& k, hipStream_t s) {
     case 9: return launch_one<T, 128, 128, 2, 2, 4, 2>(k, s);
     case 10: return launch_one<T, 128, 192, 2, 2, 3, 2>(k, s);
     case 11: return launch_one<T, 192, 128, 2, 2, 3, 4>(k, s);
+    case 12: return launch_one<T, 160, 256, 2, 2, 3, 4>(k, s);
+    case 13: return launch_one<T, 160, 192, 2, 2, 3, 4>(k, s);
   }
   return hipErrorInvalidValue;
 }
