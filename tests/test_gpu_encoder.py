@@ -254,14 +254,17 @@ def test_persistent_block17_trunk_kernel_matches_the_unfused_plan_and_the_oracle
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("n", [1, 7])
-def test_fused_block35_is_bitwise_the_five_launch_plan(monkeypatch, dt, n):
+@pytest.mark.parametrize("fuse", ["2", "18"])
+def test_fused_block35_is_bitwise_the_five_launch_plan(monkeypatch, dt, n, fuse):
     """repeat_1 (5 x Block35, inception_resnet_v1.py:36-67): one fused launch per block (block35.hip: all intermediates in
-    LDS, pixel tiles split over the waves, weights in MFMA fragment order) keeps the unfused plan's rounding points and
-    summation order, so conv2d_4b -> repeat_1 must come out bit for bit the same -- image borders (3x3 taps), the
-    padding pixels of the 19th tile and every batch position included."""
+    LDS, pixel tiles split over the waves, weights in MFMA fragment order) -- or, VNF_FUSE bit 4, ONE launch for the five
+    blocks with the residual stream in registers (trunk35.hip: x enters the reduce GEMM and the branch outputs enter the
+    up projection through lane-row swaps, never through memory) -- keeps the unfused plan's rounding points and summation
+    order, so conv2d_4b -> repeat_1 must come out bit for bit the same -- image borders (3x3 taps), the padding pixels
+    of the 19th tile and every batch position included."""
     from vn_celeb_face_recognition_amd.models import InceptionResnetV1
     x = seeded_normal((n, 3, 160, 160), 57 + n).cuda()
-    monkeypatch.setenv("VNF_FUSE", "2")      # Block35 only
+    monkeypatch.setenv("VNF_FUSE", fuse)     # Block35 only: per block (2) / the stack in one launch (18)
     fused = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=n).eval()
     yf = fused(x)
     a4, r1 = fused.tap("conv2d_4b", n), fused.tap("repeat_1", n)

@@ -33,6 +33,15 @@ hipError_t launch_block35s(const Block35Args& a, hipStream_t s);
 
 hipError_t block35_repack(const Block35Pack& p, void* out, hipStream_t s);
 hipError_t launch_block35(const Block35Args& a, int dtype, hipStream_t s);
+
+// the whole repeat_1 stack in one launch, x resident in registers (trunk35.hip; bf16 / f16 plans)
+struct Block35StackArgs {
+  const void* x;      // (n, 289, ldx) input of the first block
+  void* y;            // (n, 289, ldy) output of the last block (may alias x)
+  int ldx, ldy, n, nblocks;
+  const void* wimg;   // nblocks block35_repack images, B35_WIMG_BYTES apart
+};
+hipError_t launch_block35_stack(const Block35StackArgs& a, int dtype, hipStream_t s);
 const char* conv_zero_page();  // conv_igemm.hip: per-device page of zero bytes
 
 }  // namespace vnf

@@ -260,6 +260,200 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_ws_kernel(const
   conv_epilogue<T, BM, BN, WM, WN, EPI_LDS>(a, acc, smem, m0, n0, S * STAGE);
 }
 
+// ---- persistent form -------------------------------------------------------------------------------------------
+// One workgroup per CU walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The loader waves run the ring straight
+// across tile boundaries (K tiles of the next output tile are in flight while the consumers finish this one), and the
+// consumers store their accumulators from registers -- bias, ReLU, rounding to T, a v_permlane16_swap between the two
+// lane rows that hold neighbouring channel quads so every lane owns 8 channels = one 16-byte store -- without touching
+// LDS or a barrier.  In-kernel stamps of the one-tile-per-workgroup form (tools/stamp_patch.py): a workgroup spent 16 %
+// of its life filling the pipeline and 18-29 % in the epilogue (the store burst of 256 workgroups in lockstep runs at
+// HBM write speed); here both overlap the next tile's K loop.  Only for the layers of the fast epilogue (bias + ReLU,
+// output in T, 2-byte T).  Same K order, operand roles, fp32 sum, bias add, max and rounding: bit-identical results.
+template <typename T, int BM, int BN, int WM, int WN, int S, int LW>
+__global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_wsp_kernel(const KArgs a) {
+  static_assert(sizeof(T) == 2, "register epilogue packs 2-byte elements");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CH = 8, BKE = 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
+  constexpr int NC = WM * WN, NT = (NC + LW) * 64;
+  constexpr int PA = BM / 8, PB = BN / 8;
+  constexpr int LA = PA / LW, LB = PB / LW;
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(S >= 3 && PA % LW == 0 && PB % LW == 0 && TN % 2 == 0, "pieces divide over the loader waves");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nkt = a.nkt;
+  const int G = (int)gridDim.x;
+  const int ntile = (a.nblk - (int)blockIdx.x + G - 1) / G;  // this workgroup's tiles
+  const int Q = ntile * nkt;                                   // ... and K tiles, one barrier each
+
+  int4* sK = reinterpret_cast<int4*>(smem + S * STAGE);
+  for (int i = tid; i < nkt * 8; i += NT) sK[i] = a.ktab[i];
+  __syncthreads();
+
+  if (wave >= NC) {
+    // ------------------------------------------------------------------ loader wave
+    const int lw = wave - NC;
+    const int prow = lane >> 3, lcol = lane & 7;
+    const int lchunk = lcol ^ prow;
+    const int HoWo = a.Ho * a.Wo;
+    int abase[LA], ahi[LA], awi[LA];
+    const char* wsrc = nullptr;
+    auto setup = [&](int it) {
+      const int bid = xcd_remap((int)blockIdx.x + it * G, a.nblk);
+      const int tile_m = bid / a.tiles_n, tile_n = bid - tile_m * a.tiles_n;
+      const int m0 = tile_m * BM, n0 = tile_n * BN;
+#pragma unroll
+      for (int p = 0; p < LA; ++p) {
+        const int m = m0 + (lw + p * LW) * 8 + prow;
+        if (m < a.M) {
+          const int n = m / HoWo, r = m - n * HoWo;
+          const int ho = r / a.Wo, wo = r - ho * a.Wo;
+          ahi[p] = ho * a.sh - a.ph;
+          awi[p] = wo * a.sw - a.pw;
+          abase[p] = ((n * a.H + ahi[p]) * a.W + awi[p]) * a.ldx;
+        } else {
+          ahi[p] = -(1 << 24);
+          awi[p] = 0;
+          abase[p] = 0;
+        }
+      }
+      wsrc = a.w + (size_t)(n0 + lw * 8 + prow) * a.wrs + lchunk * 16;
+    };
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+    int it_i = 0, kt_i = 0, st_i = 0;  // issue cursor: tile ordinal, K tile inside it, ring stage
+    setup(0);
+    auto issue = [&]() {
+      const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(st_i * STAGE) + (unsigned)(lw * 1024));
+      const int4 e = sK[kt_i * 8 + lchunk];
+#pragma unroll
+      for (int p = 0; p < LA; ++p) {
+        const int hi = ahi[p] + e.y, wi = awi[p] + e.z;
+        const bool ok = e.w && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        const char* src = ok ? a.x + (size_t)(abase[p] + e.x) * 2 : a.zero;
+        glds16(src, sbase + p * (LW * 1024));
+      }
+#pragma unroll
+      for (int p = 0; p < LB; ++p)
+        glds16(wsrc + (size_t)(p * LW * 8) * a.wrs + (size_t)kt_i * a.wts, sbase + BM * 128 + p * (LW * 1024));
+      st_i = st_i + 1 == S ? 0 : st_i + 1;
+      if (++kt_i == nkt) {
+        kt_i = 0;
+        if (++it_i < ntile) setup(it_i);
+      }
+    };
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t)
+      if (t < Q) issue();
+    for (int q = 0; q < Q; ++q) {
+      if (q + S - 2 < Q)
+        wait_dma_and_barrier<(S - 2) * (LA + LB)>();
+      else
+        wait_dma_and_barrier<0>();
+      if (q + S - 1 < Q) issue();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer wave
+  const int wm = wave / WN, wn = wave % WN;
+  const int frow = lane & 15, fgrp = lane >> 4;
+  constexpr bool PIPE = (TM + TN) < 12;
+  constexpr int NF = PIPE ? 2 : 1;
+  typedef T tx4 __attribute__((ext_vector_type(4)));
+  const bool relu = a.act == ACT_RELU;
+  int st = 0;
+  for (int it = 0; it < ntile; ++it) {
+    const int bid = xcd_remap((int)blockIdx.x + it * G, a.nblk);
+    const int tile_m = bid / a.tiles_n, tile_n = bid - tile_m * a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    uint4 xf[NF][TM], wf[NF][TN];
+    auto read_frags = [&](int ks) {
+      const int fs = PIPE ? ks : 0;
+      const char* sA = smem + st * STAGE;
+      const char* sB = sA + BM * 128;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 16 + frow;
+        xf[fs][i] = *reinterpret_cast<const uint4*>(sA + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WTN + j * 16 + frow;
+        wf[fs][j] = *reinterpret_cast<const uint4*>(sB + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+      }
+    };
+    auto mma = [&](int ks) {
+      const int fs = PIPE ? ks : 0;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], wf[fs][j], xf[fs][i]);
+    };
+    bool pend = false;
+    for (int kt = 0; kt < nkt; ++kt) {
+      // no vmcnt here: this wave's only vector-memory operations are the previous tile's stores, which may still drain
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if constexpr (PIPE) {
+        read_frags(0);
+        if (pend) mma(1);
+        pend = BKE / 2 < a.K - kt * BKE;
+        if (pend) read_frags(1);
+        mma(0);
+      } else {
+        read_frags(0);
+        mma(0);
+        if (BKE / 2 < a.K - kt * BKE) {
+          read_frags(1);
+          mma(1);
+        }
+      }
+      st = st + 1 == S ? 0 : st + 1;
+    }
+    if (pend) mma(1);
+
+    // register epilogue: tiles j (even) and j+1 of a lane-row pair are exchanged so each lane holds 8 channels
+#pragma unroll
+    for (int j = 0; j < TN; j += 2) {
+      const int cq = n0 + wn * WTN + j * 16 + fgrp * 4;  // this lane's channel quad in tile j; tile j+1: +16
+      const f32x4_t b0 = cq < a.Cout ? *reinterpret_cast<const f32x4_t*>(a.bias + cq) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const f32x4_t b1 =
+          cq + 16 < a.Cout ? *reinterpret_cast<const f32x4_t*>(a.bias + cq + 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int c = n0 + wn * WTN + (j + (fgrp & 1)) * 16 + (fgrp >> 1) * 8;  // the 8 channels it stores
+      int sg = 0;
+#pragma unroll
+      for (int s2 = 1; s2 < 4; ++s2)
+        if (s2 < a.nseg && c >= a.seg_c0[s2]) sg = s2;
+      char* const dcol = a.seg_ptr[sg] + (size_t)(c - a.seg_c0[sg]) * 2;
+      const int dld = a.seg_ld[sg];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        tx4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v0 = acc[i][j][e] + b0[e], v1 = acc[i][j + 1][e] + b1[e];
+          if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+          o0[e] = (T)v0;
+          o1[e] = (T)v1;
+        }
+        const uint2 p0 = __builtin_bit_cast(uint2, o0), p1 = __builtin_bit_cast(uint2, o1);
+        // odd lane rows of p0 <-> even lane rows of p1
+        const auto sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+        const int m = m0 + wm * WTM + i * 16 + frow;
+        if (m < a.M && c < a.Cout)
+          *reinterpret_cast<uint4*>(dcol + (size_t)m * dld * 2) = uint4{sx[0], sy[0], sx[1], sy[1]};
+      }
+    }
+  }
+}
+
 // ===================================================================== host side
 struct WsCfg { int bm, bn, wm, wn, s, lw; };
 static const WsCfg kWs[] = {
@@ -285,7 +479,7 @@ bool ws_cfg_ok(const ConvArgs& a, int wcfg) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int S, int LW>
-static hipError_t launch_one(const KArgs& k, hipStream_t s) {
+static hipError_t launch_one_tile(const KArgs& k, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_ws_kernel<T, BM, BN, WM, WN, S, LW>,
@@ -301,6 +495,49 @@ static hipError_t launch_one(const KArgs& k, hipStream_t s) {
   hipLaunchKernelGGL((conv_igemm_ws_kernel<T, BM, BN, WM, WN, S, LW>), dim3(kk.nblk), dim3((WM * WN + LW) * 64), lds, s,
                      kk);
   return hipGetLastError();
+}
+
+static int cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+    n = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+// the persistent form (bias + ReLU layers of the 2-byte plans; VNF_WS_PERSIST=0 keeps one tile per workgroup)
+static bool ws_persistent(const KArgs& k) {
+  static const bool on = !(getenv("VNF_WS_PERSIST") && atoi(getenv("VNF_WS_PERSIST")) == 0);
+  return on && !k.res && k.ncls == 1 && !k.out_f32 && k.act != ACT_PRELU;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int S, int LW>
+static hipError_t launch_one(const KArgs& k, hipStream_t s) {
+  if constexpr (sizeof(T) == 2 && (BN / WN / 16) % 2 == 0) {
+    if (ws_persistent(k)) {
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_wsp_kernel<T, BM, BN, WM, WN, S, LW>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr_done = true;
+      }
+      KArgs kk = k;
+      const int lds = S * (BM + BN) * 128 + k.nkt * 8 * 16;
+      kk.tiles_n = (k.Cout + BN - 1) / BN;
+      kk.nblk = ((k.M + BM - 1) / BM) * kk.tiles_n;
+      // whole rounds of 8 workgroups keep the blockIdx -> XCD map of xcd_remap (tile t runs on XCD t % 8)
+      int grid = kk.nblk < cu_count() ? kk.nblk : cu_count() & ~7;
+      if (grid < 1) grid = kk.nblk;
+      hipLaunchKernelGGL((conv_igemm_wsp_kernel<T, BM, BN, WM, WN, S, LW>), dim3(grid), dim3((WM * WN + LW) * 64), lds,
+                         s, kk);
+      return hipGetLastError();
+    }
+  }
+  return launch_one_tile<T, BM, BN, WM, WN, S, LW>(k, s);
 }
 
 template <typename T>

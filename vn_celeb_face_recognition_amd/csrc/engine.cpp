@@ -278,8 +278,9 @@ int Encoder::finalize() {
 // Fused stacks: the per-wave weight streams are gathered on the device from the packed per-convolution weights the
 // plan already uploaded (same folding, same k order), biases are concatenated per block.
 int Encoder::prepare_fused() {
-  // bit 0: Block17 stack, bit 1: Block35, bit 2: stem 2a+2b+pool, bit 3: conv2d_3b inside the stem kernel; read at create time
-  const int enabled = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 15;
+  // bit 0: Block17 stack, bit 1: Block35, bit 2: stem 2a+2b+pool, bit 3: conv2d_3b inside the stem kernel, bit 4: the five
+  // Block35 in one launch (with bit 1); read at create time
+  const int enabled = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 31;
   for (FusedStack& f : fused) {
     f.active = false;
     if (!enabled || (dtype != BF16 && dtype != F16 && dtype != F16P) || f.nblocks < 1 || f.nblocks > T17_MAX_BLOCKS) continue;
@@ -337,6 +338,7 @@ int Encoder::prepare_fused() {
       }
       VNF_HIP(hipDeviceSynchronize());
       f.active = true;
+      f.stack = (enabled & 16) && dtype != F16P;
       continue;
     }
     if (!(enabled & 1)) continue;
@@ -755,7 +757,7 @@ int build_irv1(Encoder& e, WeightMap& wm) {
   // unfused, the stem runs in sub-batches of 128 images so its big producer -> consumer tensors stay inside the
   // Infinity Cache; with conv2d_2a/2b/maxpool fused (one workgroup per image, no big intermediate) a sub-batch would
   // only leave half the CUs without a workgroup
-  const int fuse_mask = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 15;
+  const int fuse_mask = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 31;
   int chunk = ((fuse_mask & 4) && (e.dtype == BF16 || e.dtype == F16 || (e.dtype == F16P && (fuse_mask & 8)))) ? 256 : 128;
   if (const char* c = getenv("VNF_STEM_CHUNK")) chunk = atoi(c) > 0 ? atoi(c) : chunk;
   e.groups.push_back({0, stem_end, chunk});
@@ -1345,6 +1347,19 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
           oi = (fs->ext ? fs->ext_last : fs->last) - 1;
           continue;
         }
+        if (fs && fs->kind == 35 && fs->stack) {
+          const Buf& ib = bufs[convs[fs->conv0 + 4].res_buf];                               // first block's input
+          const Buf& ob = bufs[convs[fs->conv0 + 5 * (fs->nblocks - 1) + 4].seg[0].buf];    // last block's output
+          Block35StackArgs ba;
+          ba.x = ib.ptr + (size_t)n0 * ib.elems_per_image() * es;
+          ba.y = ob.ptr + (size_t)n0 * ob.elems_per_image() * es;
+          ba.ldx = ib.C; ba.ldy = ob.C; ba.n = nn; ba.nblocks = fs->nblocks;
+          ba.wimg = fs->wstream;
+          hipError_t err = launch_block35_stack(ba, dtype, s);
+          if (err != hipSuccess) return fail(VNF_E_HIP, std::string("fused Block35 stack: ") + hipGetErrorString(err));
+          oi = fs->last - 1;
+          continue;
+        }
         if (fs && fs->kind == 35) {
           for (int b = 0; b < fs->nblocks; ++b) {
             const ConvLayer& up = convs[fs->conv0 + 5 * b + 4];   // residual source = block input, segment 0 = block output
@@ -1492,7 +1507,8 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
         const double gf = 2.0 * fs->macs_alg * n / 1e9;
         snprintf(line, sizeof line, "%-28s %-60s %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n",
                  fs->kind == 35 ? "repeat_1 (fused blocks)" : fs->kind == 2 ? (fs->ext ? "conv2d_2a+2b+maxpool_3a+3b" : "conv2d_2a+2b+maxpool_3a") : "repeat_2 (persistent trunk)",
-                 fs->kind == 35 ? "5 x Block35, one launch per block, one workgroup per image"
+                 fs->kind == 35 ? (fs->stack ? "5 x Block35 in one launch, x in registers, one workgroup per image"
+                                             : "5 x Block35, one launch per block, one workgroup per image")
                  : fs->kind == 2 ? "rolling rows, one launch, one workgroup per image"
                                  : "10 x Block17 in one launch, one workgroup per image",
                  ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);

@@ -101,6 +101,7 @@ struct FusedStack {
   void* wstream = nullptr;
   float* bias = nullptr;
   bool active = false;
+  bool stack = false;          // kind 35: the five blocks in ONE launch, x resident in registers (trunk35.hip; bf16 / f16)
   double macs_alg = 0;         // per image
   // kind 2 only: conv2d_3b (the op after the pool) folded into the stem kernel: ops [first, ext_last) become one launch
   int ext_last = 0, ext_conv = -1, ext_out_buf = -1;
