@@ -40,6 +40,7 @@ struct Block35StackArgs {
   void* y;            // (n, 289, ldy) output of the last block (may alias x)
   int ldx, ldy, n, nblocks;
   const void* wimg;   // nblocks block35_repack images, B35_WIMG_BYTES apart
+  long long* dbg = nullptr;  // in-kernel stamp buffer of the instrumented launch (tools), else null
 };
 hipError_t launch_block35_stack(const Block35StackArgs& a, int dtype, hipStream_t s);
 const char* conv_zero_page();  // conv_igemm.hip: per-device page of zero bytes

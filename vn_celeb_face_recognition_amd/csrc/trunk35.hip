@@ -26,6 +26,8 @@
 //   [49152, 98304)     W5 (up, 48 fragments), loaded under phases A-D
 //   [98304, 135168)    two 3x3 weight buffers (18 fragments each): W2 | W3 prefetched under phase E, W4 under phase C
 //   [135168, 139264)   the blocks' 448 fp32 biases, double-buffered by block parity
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "block35.h"
@@ -93,9 +95,28 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // NT = pixel tiles of the wave (wave, wave + 8, wave + 16: three for waves 0-2, two for the rest) as a compile-time
 // constant: with a run-time tile count around the third tile its registers are conditionally defined everywhere and the
 // allocator spills ~800 bytes
-template <typename T, int NT>
+template <typename T, int NT, bool DBG>
 __device__ __forceinline__ void block35_stack_body(const Block35StackArgs& a, char* smem, const int wave) {
   const int tid = threadIdx.x, lane = tid & 63;
+  // instrumented build (VNF_T35_STAMP): cycles per phase segment summed over the blocks, in scalar registers (the
+  // segment ids follow the stamp() calls in program order: 0 = prologue, 1 = first wait, then per block 12 segments)
+  long long tsum[16];
+  long long tlast = 0;
+  int nstamp = 0;
+  if constexpr (DBG) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tsum[i] = 0;
+    tlast = __builtin_readcyclecounter();
+  }
+  auto stamp = [&](int seg) {
+    if constexpr (DBG) {
+      const long long t = __builtin_readcyclecounter();
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i == seg) tsum[i] += t - tlast;
+      tlast = t;
+    }
+  };
   const int frow = lane & 15, fgrp = lane >> 4;
   const int img = blockIdx.x;
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
@@ -142,20 +163,20 @@ __device__ __forceinline__ void block35_stack_body(const Block35StackArgs& a, ch
     }
   prefetch_front(0);
   copy_lin((const char*)a.wimg + B35_W5, OFF_W5, 48, C6{});
+  stamp(0);
   wait_vm<0>();
   __syncthreads();
+  stamp(1);
 
-  // pixel coordinates of this lane's rows (3x3 taps)
-  int py[NT], px[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int p = 16 * (wave + 8 * i) + frow;
-    py[i] = p < NPX ? p / IMW : -100;
-    px[i] = p - (p / IMW) * IMW;
-  }
-
+  const int lane_k = lane;
 #pragma unroll 1
   for (int b = 0; b < a.nblocks; ++b) {
+    // Every LDS address below is invariant over the blocks, and the compiler would hoist a few hundred of them out of
+    // this loop into registers it does not have (they spill).  Re-deriving them from a value it cannot see through
+    // keeps them where they are used.
+    int lane = lane_k;
+    asm volatile("" : "+v"(lane));
+    const int frow = lane & 15, fgrp = lane >> 4;
     const char* wi = (const char*)a.wimg + (size_t)b * B35_WIMG_BYTES;
     const float* bias = reinterpret_cast<const float*>(smem + OFF_BIAS + (b & 1) * 2048);
     uint4 cf[3][NT];  // concat fragments of the up projection: [k-step = b0, b1, b2][pixel tile]
@@ -171,22 +192,31 @@ __device__ __forceinline__ void block35_stack_body(const Block35StackArgs& a, ch
         for (int j = 0; j < 3; ++j)
 #pragma unroll
           for (int i = 0; i < NT; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          uint4 xf[NT], wf[3];
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-            wf[j] = *reinterpret_cast<const uint4*>(smem + OFF_W1 + (ks * 6 + 3 * jh + j) * 1024 + lane * 16);
-#pragma unroll
-          for (int i = 0; i < NT; ++i)
-            xf[i] = quads_to_frag(xr[i][2 * ks], xr[i][2 * ks + 1]);
+        // software-pipelined by hand: the weight fragments and the lane-row swaps of k-step ks+1 are issued before the
+        // MFMAs of k-step ks (with two waves per SIMD nothing else hides the LDS latency and the swaps' VALU time)
+        uint4 xf[2][NT], wf[2][3];
+        auto fetch = [&](auto KS, auto C) {
+          constexpr int ks = decltype(KS)::value, c = decltype(C)::value;
 #pragma unroll
           for (int j = 0; j < 3; ++j)
+            wf[c][j] = *reinterpret_cast<const uint4*>(smem + OFF_W1 + (ks * 6 + 3 * jh + j) * 1024 + lane * 16);
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
-              acc[j][i] = Mma<T>::run(wf[j], xf[i], acc[j][i]);
-          __builtin_amdgcn_sched_barrier(0);  // one k-step's fragments at a time
-        }
+          for (int i = 0; i < NT; ++i) xf[c][i] = quads_to_frag(xr[i][2 * ks], xr[i][2 * ks + 1]);
+        };
+        auto step = [&](auto KS) {
+          constexpr int ks = decltype(KS)::value, c = ks & 1;
+          if constexpr (ks + 1 < 8) fetch(std::integral_constant<int, ks + 1>{}, std::integral_constant<int, c ^ 1>{});
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[j][i] = Mma<T>::run(wf[c][j], xf[c][i], acc[j][i]);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
 #pragma unroll
         for (int i = 0; i < NT; ++i)
           {
@@ -202,7 +232,9 @@ __device__ __forceinline__ void block35_stack_body(const Block35StackArgs& a, ch
           }
         __builtin_amdgcn_sched_barrier(0);
       }
+      stamp(2);
       __syncthreads();  // W1 is dead: the images (which overlay it) may be written
+      stamp(3);
       // b0 (channel tiles 0,1) stays in registers as the first concat fragment; t1 (2,3) -> image 0, t2 (4,5) -> image 1
 #pragma unroll
       for (int i = 0; i < NT; ++i)
@@ -215,9 +247,19 @@ __device__ __forceinline__ void block35_stack_body(const Block35StackArgs& a, ch
               *reinterpret_cast<uint2*>(smem + ((j >> 1) - 1) * IMG_BYTES + img_chunk(p, 2 * (j & 1) + (fgrp >> 1)) + (fgrp & 1) * 8) = qa[i][j];
           }
         }
+      stamp(4);
       __syncthreads();
+      stamp(5);
     }
 
+    // pixel coordinates of this lane's rows (3x3 taps); derived here, not above phase A, whose registers are all taken
+    int py[NT], px[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int p = 16 * (wave + 8 * i) + frow;
+      py[i] = p < NPX ? p / IMW : -100;
+      px[i] = p - (p / IMW) * IMW;
+    }
     // ================================================================= phases B, C, D: 3x3 pad 1, 32 -> 32
     //   B: image 0 (t1) -> b1 (registers), W2 | C: image 1 (t2) -> image 0 (t2b), W3 | D: image 0 -> b2 (registers), W4
 #pragma unroll
@@ -272,8 +314,10 @@ __device__ __forceinline__ void block35_stack_body(const Block35StackArgs& a, ch
             cf[ph == 0 ? 1 : 2][i] = quads_to_frag(q[0], q[1]);
           }
         }
+      stamp(6);
       if (ph == 1) wait_vm<0>();  // W4 (issued after B) and W5 have landed before the barrier that opens D / E
       __syncthreads();
+      stamp(7);
       if (ph == 0) copy_lin(wi + B35_W4, OFF_W33, 18, C3{});  // W2 is dead
     }
     // images and both 3x3 buffers are dead: the next block's bias, W1, W2 | W3 travel under phase E
@@ -316,20 +360,32 @@ __device__ __forceinline__ void block35_stack_body(const Block35StackArgs& a, ch
         }
       __builtin_amdgcn_sched_barrier(0);
     }
+    stamp(8);
     wait_vm<0>();     // the next block's bias, W1, W2 | W3 (this wave's pieces) have landed
     __syncthreads();  // ... everybody's; and W5 is dead
+    stamp(9);
     copy_lin((const char*)a.wimg + (size_t)min(b + 1, a.nblocks - 1) * B35_WIMG_BYTES + B35_W5, OFF_W5, 48, C6{});
   }
   wait_vm<0>();  // the redundant last prefetch: no DMA may be in flight into a workgroup's LDS when it ends
 
+  if constexpr (DBG) {
+    if (a.dbg && blockIdx.x == 100 && (threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a.dbg[wave * 64 + i] = tsum[i];
+    }
+  }
   // ---- x registers -> y: the lane-row swap gives every lane 8 consecutive channels = one 16-byte store
+  // (addresses from an opaque lane id again: computed up front they would sit in registers -- spilled -- all kernel long)
+  int lane_y = lane_k;
+  asm volatile("" : "+v"(lane_y));
+  const int frow_y = lane_y & 15, fgrp_y = lane_y >> 4;
 #pragma unroll
   for (int i = 0; i < NT; ++i)
     {
-      const int p = 16 * (wave + 8 * i) + frow;
+      const int p = 16 * (wave + 8 * i) + frow_y;
 #pragma unroll
       for (int jp = 0; jp < 8; ++jp) {
-        const int c = (2 * jp + (fgrp & 1)) * 16 + (fgrp >> 1) * 8;
+        const int c = (2 * jp + (fgrp_y & 1)) * 16 + (fgrp_y >> 1) * 8;
         const uint2 p0 = xr[i][2 * jp], p1 = xr[i][2 * jp + 1];
         const auto sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
         const auto sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
@@ -338,14 +394,42 @@ __device__ __forceinline__ void block35_stack_body(const Block35StackArgs& a, ch
     }
 }
 
-template <typename T>
+template <typename T, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void block35_stack_kernel(const Block35StackArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wave < 3)
-    block35_stack_body<T, 3>(a, smem, wave);
+    block35_stack_body<T, 3, DBG>(a, smem, wave);
   else
-    block35_stack_body<T, 2>(a, smem, wave);
+    block35_stack_body<T, 2, DBG>(a, smem, wave);
+}
+
+// Instrumented launch: VNF_T35_STAMP=<file> appends the stamps of workgroup 100 (bf16, n > 100): per wave
+//   start | x loaded, weights issued | first barrier | per block: A done, barrier, images written, barrier, then for
+//   B, C, D: phase done, barrier; E done, barrier
+static hipError_t launch_stack_stamped(const Block35StackArgs& a, hipStream_t s) {
+  static long long* dbuf = nullptr;
+  const int n = 8 * 64;
+  if (!dbuf && hipMalloc((void**)&dbuf, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+  (void)hipMemsetAsync(dbuf, 0, n * 8, s);
+  Block35StackArgs aa = a;
+  aa.dbg = dbuf;
+  (void)hipFuncSetAttribute((const void*)block35_stack_kernel<__bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T35_LDS);
+  hipLaunchKernelGGL((block35_stack_kernel<__bf16, true>), dim3(a.n), dim3(512), T35_LDS, s, aa);
+  hipError_t e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return e;
+  static long long host[8 * 64];
+  (void)hipMemcpy(host, dbuf, n * 8, hipMemcpyDeviceToHost);
+  if (FILE* f = fopen(getenv("VNF_T35_STAMP"), "a")) {
+    fprintf(f, "launch n=%d nblocks=%d\n", a.n, a.nblocks);
+    for (int w = 0; w < 8; ++w) {
+      fprintf(f, "%d", w);
+      for (int i = 0; i < 10; ++i) fprintf(f, " %lld", host[w * 64 + i]);
+      fprintf(f, "\n");
+    }
+    fclose(f);
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_block35_stack(const Block35StackArgs& a, int dtype, hipStream_t s) {
@@ -357,6 +441,7 @@ hipError_t launch_block35_stack(const Block35StackArgs& a, int dtype, hipStream_
     (void)hipGetLastError();
     attr_done = true;
   }
+  if (dtype == BF16 && a.n > 100 && getenv("VNF_T35_STAMP")) return launch_stack_stamped(a, s);
   if (dtype == BF16)
     hipLaunchKernelGGL(block35_stack_kernel<__bf16>, dim3(a.n), dim3(512), T35_LDS, s, a);
   else if (dtype == F16)
