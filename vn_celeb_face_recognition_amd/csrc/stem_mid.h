@@ -19,6 +19,7 @@ struct StemMidArgs {
   const void* w3b;     // packed engine weights [>= 80 rows][k3b_pad], 16-bit; nullptr: no fusion
   const float* b3b;    // [80]
   int k3b_pad;
+  long long* dbg = nullptr;   // in-kernel timer buffer of the instrumented launch (tools), else null
 };
 
 struct StemMidPack {    // packed engine weights [rows][kpad], k = (kh, kw, c): conv2d_2a (32 x 288), conv2d_2b (64 x 288)
