@@ -271,9 +271,10 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_ws_kernel(const
 // output in T, 2-byte T).  Same K order, operand roles, fp32 sum, bias add, max and rounding: bit-identical results.
 template <typename T, int BM, int BN, int WM, int WN, int S, int LW>
 __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_wsp_kernel(const KArgs a) {
-  static_assert(sizeof(T) == 2, "register epilogue packs 2-byte elements");
+  static_assert(sizeof(T) == 2 || is_planar<T>::value, "register epilogue: 2-byte elements or planar split-f16 units");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int CH = 8, BKE = 64;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int BKE = 128 / ES;
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
   constexpr int NC = WM * WN, NT = (NC + LW) * 64;
   constexpr int PA = BM / 8, PB = BN / 8;
@@ -331,7 +332,7 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_wsp_kernel(cons
       for (int p = 0; p < LA; ++p) {
         const int hi = ahi[p] + e.y, wi = awi[p] + e.z;
         const bool ok = e.w && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-        const char* src = ok ? a.x + (size_t)(abase[p] + e.x) * 2 : a.zero;
+        const char* src = ok ? a.x + (size_t)(abase[p] + e.x) * ES : a.zero;
         glds16(src, sbase + p * (LW * 1024));
       }
 #pragma unroll
@@ -361,7 +362,8 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_wsp_kernel(cons
   const int frow = lane & 15, fgrp = lane >> 4;
   constexpr bool PIPE = (TM + TN) < 12;
   constexpr int NF = PIPE ? 2 : 1;
-  typedef T tx4 __attribute__((ext_vector_type(4)));
+  typedef typename std::conditional<is_planar<T>::value, _Float16, T>::type elem_t;
+  typedef elem_t tx4 __attribute__((ext_vector_type(4)));
   const bool relu = a.act == ACT_RELU;
   int st = 0;
   for (int it = 0; it < ntile; ++it) {
@@ -396,10 +398,75 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_wsp_kernel(cons
 #pragma unroll
         for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], wf[fs][j], xf[fs][i]);
     };
-    bool pend = false;
-    for (int kt = 0; kt < nkt; ++kt) {
+    auto join = [&]() {
       // no vmcnt here: this wave's only vector-memory operations are the previous tile's stores, which may still drain
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    if constexpr (is_planar<T>::value) {
+      // planar split-f16 (see conv_igemm.hip): half 0 / 1 of a K tile = hi / lo plane of the same 32 k values
+      uint4 xh[NF][TM], wh[NF][TN], xl[TM], wl[TN];
+      auto rd = [&](int ks, uint4 (&x)[TM], uint4 (&w)[TN]) {
+        const char* sA = smem + st * STAGE;
+        const char* sB = sA + BM * 128;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = wm * WTM + i * 16 + frow;
+          x[i] = *reinterpret_cast<const uint4*>(sA + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = wn * WTN + j * 16 + frow;
+          w[j] = *reinterpret_cast<const uint4*>(sB + row * 128 + (((ks * 4 + fgrp) ^ (row & 7)) << 4));
+        }
+      };
+      auto cross = [&](uint4 (&x)[TM], uint4 (&w)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) mma_cross(acc[i][j], w[j], wl[j], x[i], xl[i]);
+      };
+      auto hh = [&](uint4 (&x)[TM], uint4 (&w)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) mma_hh(acc[i][j], w[j], x[i]);
+      };
+      auto next_stage = [&]() { st = st + 1 == S ? 0 : st + 1; };
+      if constexpr (PIPE) {
+        auto step = [&](auto P, bool first) {
+          constexpr int c = decltype(P)::value;
+          join();
+          rd(0, xh[c], wh[c]);
+          if (!first) cross(xh[c ^ 1], wh[c ^ 1]);
+          rd(1, xl, wl);
+          hh(xh[c], wh[c]);
+          next_stage();
+        };
+        int kt = 0;
+        for (; kt + 1 < nkt; kt += 2) {
+          step(std::integral_constant<int, 0>{}, kt == 0);
+          step(std::integral_constant<int, 1>{}, false);
+        }
+        if (kt < nkt) {
+          step(std::integral_constant<int, 0>{}, kt == 0);
+          cross(xh[0], wh[0]);
+        } else {
+          cross(xh[NF - 1], wh[NF - 1]);
+        }
+      } else {
+        for (int kt = 0; kt < nkt; ++kt) {
+          join();
+          rd(0, xh[0], wh[0]);
+          rd(1, xl, wl);
+          hh(xh[0], wh[0]);
+          cross(xh[0], wh[0]);
+          next_stage();
+        }
+      }
+    } else {
+    bool pend = false;
+    for (int kt = 0; kt < nkt; ++kt) {
+      join();
       if constexpr (PIPE) {
         read_frags(0);
         if (pend) mma(1);
@@ -417,6 +484,7 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_wsp_kernel(cons
       st = st + 1 == S ? 0 : st + 1;
     }
     if (pend) mma(1);
+    }
 
     // register epilogue: tiles j (even) and j+1 of a lane-row pair are exchanged so each lane holds 8 channels
 #pragma unroll
@@ -430,25 +498,50 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_wsp_kernel(cons
 #pragma unroll
       for (int s2 = 1; s2 < 4; ++s2)
         if (s2 < a.nseg && c >= a.seg_c0[s2]) sg = s2;
-      char* const dcol = a.seg_ptr[sg] + (size_t)(c - a.seg_c0[sg]) * 2;
+      char* const dcol = a.seg_ptr[sg] + (size_t)(c - a.seg_c0[sg]) * ES;
       const int dld = a.seg_ld[sg];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        tx4 o0, o1;
+        float v0[4], v1[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v0 = acc[i][j][e] + b0[e], v1 = acc[i][j + 1][e] + b1[e];
-          if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-          o0[e] = (T)v0;
-          o1[e] = (T)v1;
+          v0[e] = acc[i][j][e] + b0[e];
+          v1[e] = acc[i][j + 1][e] + b1[e];
+          if (relu) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
         }
-        const uint2 p0 = __builtin_bit_cast(uint2, o0), p1 = __builtin_bit_cast(uint2, o1);
-        // odd lane rows of p0 <-> even lane rows of p1
-        const auto sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
-        const auto sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
         const int m = m0 + wm * WTM + i * 16 + frow;
-        if (m < a.M && c < a.Cout)
-          *reinterpret_cast<uint4*>(dcol + (size_t)m * dld * 2) = uint4{sx[0], sy[0], sx[1], sy[1]};
+        if constexpr (is_planar<T>::value) {
+          // an 8-channel unit is [8 hi][8 lo]: the hi quads and the lo quads are exchanged separately
+          typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+          h4 h0, l0, h1, l1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const sf16 s0(v0[e]), s1(v1[e]);
+            h0[e] = s0.hi; l0[e] = s0.lo;
+            h1[e] = s1.hi; l1[e] = s1.lo;
+          }
+          const uint2 ph0 = __builtin_bit_cast(uint2, h0), ph1 = __builtin_bit_cast(uint2, h1);
+          const uint2 pl0 = __builtin_bit_cast(uint2, l0), pl1 = __builtin_bit_cast(uint2, l1);
+          const auto hx = __builtin_amdgcn_permlane16_swap(ph0.x, ph1.x, false, false);
+          const auto hy = __builtin_amdgcn_permlane16_swap(ph0.y, ph1.y, false, false);
+          const auto lx = __builtin_amdgcn_permlane16_swap(pl0.x, pl1.x, false, false);
+          const auto ly = __builtin_amdgcn_permlane16_swap(pl0.y, pl1.y, false, false);
+          if (m < a.M && c < a.Cout) {
+            char* d = dcol + (size_t)m * dld * ES;
+            *reinterpret_cast<uint4*>(d) = uint4{hx[0], hy[0], hx[1], hy[1]};
+            *reinterpret_cast<uint4*>(d + 16) = uint4{lx[0], ly[0], lx[1], ly[1]};
+          }
+        } else {
+          tx4 o0, o1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o0[e] = (elem_t)v0[e]; o1[e] = (elem_t)v1[e]; }
+          const uint2 p0 = __builtin_bit_cast(uint2, o0), p1 = __builtin_bit_cast(uint2, o1);
+          // odd lane rows of p0 <-> even lane rows of p1
+          const auto sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+          const auto sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+          if (m < a.M && c < a.Cout)
+            *reinterpret_cast<uint4*>(dcol + (size_t)m * dld * ES) = uint4{sx[0], sy[0], sx[1], sy[1]};
+        }
       }
     }
   }
@@ -516,7 +609,7 @@ static bool ws_persistent(const KArgs& k) {
 
 template <typename T, int BM, int BN, int WM, int WN, int S, int LW>
 static hipError_t launch_one(const KArgs& k, hipStream_t s) {
-  if constexpr (sizeof(T) == 2 && (BN / WN / 16) % 2 == 0) {
+  if constexpr ((sizeof(T) == 2 || is_planar<T>::value) && (BN / WN / 16) % 2 == 0) {
     if (ws_persistent(k)) {
       static bool attr_done = false;
       if (!attr_done) {
