@@ -268,8 +268,11 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_ws_kernel(const
 // LDS or a barrier.  In-kernel stamps of the one-tile-per-workgroup form (tools/stamp_patch.py): a workgroup spent 16 %
 // of its life filling the pipeline and 18-29 % in the epilogue (the store burst of 256 workgroups in lockstep runs at
 // HBM write speed); here both overlap the next tile's K loop.  Only for the layers of the fast epilogue (bias + ReLU,
-// output in T, 2-byte T).  Same K order, operand roles, fp32 sum, bias add, max and rounding: bit-identical results.
-template <typename T, int BM, int BN, int WM, int WN, int S, int LW>
+// output in T, 2-byte T or planar split-f16).  RES: a residual operand (Block8's up projection, small tiles only): its
+// 16-byte chunks are fetched at the START of the tile -- behind the K loop they would wait, vmcnt being in issue order,
+// for the previous tile's stores -- and un-swapped into the accumulator layout in the epilogue.  Same K order, operand
+// roles, fp32 sum, bias add, residual add, max and rounding: bit-identical results.
+template <typename T, int BM, int BN, int WM, int WN, int S, int LW, bool RES = false>
 __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_wsp_kernel(const KArgs a) {
   static_assert(sizeof(T) == 2 || is_planar<T>::value, "register epilogue: 2-byte elements or planar split-f16 units");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -375,6 +378,17 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_wsp_kernel(cons
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    uint4 rres[RES ? TM : 1][RES ? TN / 2 : 1];
+    if constexpr (RES) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jp = 0; jp < TN / 2; ++jp) {
+          const int c = n0 + wn * WTN + (2 * jp + (fgrp & 1)) * 16 + (fgrp >> 1) * 8;
+          const int m = min(m0 + wm * WTM + i * 16 + frow, a.M - 1);
+          rres[i][jp] = *reinterpret_cast<const uint4*>(a.res + ((size_t)m * a.ldres + (c < a.Cout ? c : 0)) * ES);
+        }
+    }
     uint4 xf[NF][TM], wf[NF][TN];
     auto read_frags = [&](int ks) {
       const int fs = PIPE ? ks : 0;
@@ -507,7 +521,19 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_wsp_kernel(cons
         for (int e = 0; e < 4; ++e) {
           v0[e] = acc[i][j][e] + b0[e];
           v1[e] = acc[i][j + 1][e] + b1[e];
-          if (relu) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+        }
+        if constexpr (RES) {
+          // the chunk this lane will store holds, swapped, the residual of its two accumulator quads
+          const uint4 r = rres[i][j / 2];
+          const auto rx = __builtin_amdgcn_permlane16_swap(r.x, r.z, false, false);
+          const auto ry = __builtin_amdgcn_permlane16_swap(r.y, r.w, false, false);
+          const tx4 q0 = __builtin_bit_cast(tx4, uint2{rx[0], ry[0]}), q1 = __builtin_bit_cast(tx4, uint2{rx[1], ry[1]});
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v0[e] += (float)q0[e]; v1[e] += (float)q1[e]; }
+        }
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
         }
         const int m = m0 + wm * WTM + i * 16 + frow;
         if constexpr (is_planar<T>::value) {
@@ -556,6 +582,9 @@ static const WsCfg kWs[] = {
     // 160-row tiles: the 17x17 layers' 73,984 pixels are 578 tiles of 128 = 2.26 rounds over 256 CUs (a third round for a
     // quarter of them) but 463 tiles of 160 = 1.81
     {160, 256, 2, 2, 3, 4}, {160, 192, 2, 2, 3, 4},
+    // small tiles for the 3x3-pixel tail (M = 9 rows per image): persistent, so their 6-28 K tiles per output tile run
+    // back to back instead of each paying a pipeline fill and an epilogue
+    {64, 64, 2, 2, 4, 4},   {64, 128, 2, 2, 4, 4},  {32, 64, 2, 2, 6, 4},   {32, 128, 2, 2, 4, 4},  {64, 64, 2, 2, 8, 4},
 };
 constexpr int kNumWs = (int)(sizeof(kWs) / sizeof(kWs[0]));
 
@@ -604,30 +633,40 @@ static int cu_count() {
 // the persistent form (bias + ReLU layers of the 2-byte plans; VNF_WS_PERSIST=0 keeps one tile per workgroup)
 static bool ws_persistent(const KArgs& k) {
   static const bool on = !(getenv("VNF_WS_PERSIST") && atoi(getenv("VNF_WS_PERSIST")) == 0);
-  return on && !k.res && k.ncls == 1 && !k.out_f32 && k.act != ACT_PRELU;
+  return on && k.ncls == 1 && !k.out_f32 && k.act != ACT_PRELU;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int S, int LW, bool RES>
+static hipError_t launch_persistent(const KArgs& k, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm_wsp_kernel<T, BM, BN, WM, WN, S, LW, RES>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  KArgs kk = k;
+  const int lds = S * (BM + BN) * 128 + k.nkt * 8 * 16;
+  kk.tiles_n = (k.Cout + BN - 1) / BN;
+  kk.nblk = ((k.M + BM - 1) / BM) * kk.tiles_n;
+  // one workgroup per CU per LDS-resident copy; whole rounds of 8 workgroups keep the blockIdx -> XCD map of xcd_remap
+  // (tile t runs on XCD t % 8)
+  const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+  int grid = kk.nblk < cu_count() * per_cu ? kk.nblk : (cu_count() * per_cu) & ~7;
+  if (grid < 1) grid = kk.nblk;
+  hipLaunchKernelGGL((conv_igemm_wsp_kernel<T, BM, BN, WM, WN, S, LW, RES>), dim3(grid), dim3((WM * WN + LW) * 64), lds, s,
+                     kk);
+  return hipGetLastError();
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int S, int LW>
 static hipError_t launch_one(const KArgs& k, hipStream_t s) {
   if constexpr ((sizeof(T) == 2 || is_planar<T>::value) && (BN / WN / 16) % 2 == 0) {
     if (ws_persistent(k)) {
-      static bool attr_done = false;
-      if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_wsp_kernel<T, BM, BN, WM, WN, S, LW>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipGetLastError();
-        attr_done = true;
-      }
-      KArgs kk = k;
-      const int lds = S * (BM + BN) * 128 + k.nkt * 8 * 16;
-      kk.tiles_n = (k.Cout + BN - 1) / BN;
-      kk.nblk = ((k.M + BM - 1) / BM) * kk.tiles_n;
-      // whole rounds of 8 workgroups keep the blockIdx -> XCD map of xcd_remap (tile t runs on XCD t % 8)
-      int grid = kk.nblk < cu_count() ? kk.nblk : cu_count() & ~7;
-      if (grid < 1) grid = kk.nblk;
-      hipLaunchKernelGGL((conv_igemm_wsp_kernel<T, BM, BN, WM, WN, S, LW>), dim3(grid), dim3((WM * WN + LW) * 64), lds,
-                         s, kk);
-      return hipGetLastError();
+      if (!k.res) return launch_persistent<T, BM, BN, WM, WN, S, LW, false>(k, s);
+      // residual chunks live in registers for the whole K loop: small tiles only
+      if constexpr (sizeof(T) == 2 && (BM / WM / 16) * (BN / WN / 32) <= 8)
+        return launch_persistent<T, BM, BN, WM, WN, S, LW, true>(k, s);
     }
   }
   return launch_one_tile<T, BM, BN, WM, WN, S, LW>(k, s);
@@ -650,6 +689,11 @@ static hipError_t launch_ws_typed(int wcfg, const KArgs& k, hipStream_t s) {
     case 11: return launch_one<T, 192, 128, 2, 2, 3, 4>(k, s);
     case 12: return launch_one<T, 160, 256, 2, 2, 3, 4>(k, s);
     case 13: return launch_one<T, 160, 192, 2, 2, 3, 4>(k, s);
+    case 14: return launch_one<T, 64, 64, 2, 2, 4, 4>(k, s);
+    case 15: return launch_one<T, 64, 128, 2, 2, 4, 4>(k, s);
+    case 16: return launch_one<T, 32, 64, 2, 2, 6, 4>(k, s);
+    case 17: return launch_one<T, 32, 128, 2, 2, 4, 4>(k, s);
+    case 18: return launch_one<T, 64, 64, 2, 2, 8, 4>(k, s);
   }
   return hipErrorInvalidValue;
 }
