@@ -193,7 +193,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 // ---- epilogue shared by the conv kernels: fp32 accumulators -> LDS -> whole NHWC rows ------------
-// Fast form (the stem / reduction convolutions of the 2-byte plans: bias + ReLU only, no residual, no border-class bias,
+// Fast form (the stem / reduction convolutions of the 2-byte plans: bias + ReLU / PReLU, no residual, no border-class bias,
 // output in T): bias and activation are applied in the accumulator layout, the tile is staged ALREADY ROUNDED to T --
 // half the LDS bytes, so the whole tile fits one pass and one barrier -- and every global load (the bias) is issued
 // before the first store: vmcnt counts loads and stores together in issue order, so a load behind a store waits for
@@ -205,7 +205,7 @@ __device__ __forceinline__ bool conv_epilogue_is_fast(const KArgs& a, int avail)
   if constexpr (sizeof(T) != 2)
     return false;
   else
-    return !a.res && a.ncls == 1 && !a.out_f32 && a.act != ACT_PRELU && BM * (BN * 2 + 16) <= avail;
+    return !a.res && a.ncls == 1 && !a.out_f32 && BM * (BN * 2 + 16) <= avail;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int LDS_BYTES>
@@ -228,20 +228,27 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, f32x4_t (&acc)[BM 
         const int c = n0 + wn * WTN + j * 16 + fgrp * 4;
         bias[j] = c < a.Cout ? *reinterpret_cast<const f32x4_t*>(a.bias + c) : f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
-      const bool relu = a.act == ACT_RELU;
+      const bool relu = a.act == ACT_RELU, prelu = a.act == ACT_PRELU;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j) {
+        f32x4_t slope = {0.f, 0.f, 0.f, 0.f};
+        if (prelu) {
+          const int c = n0 + wn * WTN + j * 16 + fgrp * 4;
+          if (c < a.Cout) slope = *reinterpret_cast<const f32x4_t*>(a.slope + c);
+        }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int i = 0; i < TM; ++i) {
           tx4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = acc[i][j][e] + bias[j][e];
             if (relu) v = fmaxf(v, 0.f);
+            if (prelu) v = v > 0.f ? v : v * slope[e];
             o[e] = (T)v;
           }
           *reinterpret_cast<tx4*>(smem + (wm * WTM + i * 16 + frow) * PITCH + (wn * WTN + j * 16 + fgrp * 4) * 2) = o;
         }
+      }
       __syncthreads();
       constexpr int CPR8 = BN / 8;
       for (int idx = tid; idx < BM * CPR8; idx += NT) {

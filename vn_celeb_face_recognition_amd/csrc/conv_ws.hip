@@ -367,7 +367,7 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_wsp_kernel(cons
   constexpr int NF = PIPE ? 2 : 1;
   typedef typename std::conditional<is_planar<T>::value, _Float16, T>::type elem_t;
   typedef elem_t tx4 __attribute__((ext_vector_type(4)));
-  const bool relu = a.act == ACT_RELU;
+  const bool relu = a.act == ACT_RELU, prelu = a.act == ACT_PRELU;
   int st = 0;
   for (int it = 0; it < ntile; ++it) {
     const int bid = xcd_remap((int)blockIdx.x + it * G, a.nblk);
@@ -507,6 +507,11 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_wsp_kernel(cons
       const f32x4_t b0 = cq < a.Cout ? *reinterpret_cast<const f32x4_t*>(a.bias + cq) : f32x4_t{0.f, 0.f, 0.f, 0.f};
       const f32x4_t b1 =
           cq + 16 < a.Cout ? *reinterpret_cast<const f32x4_t*>(a.bias + cq + 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+      if (prelu) {
+        if (cq < a.Cout) s0 = *reinterpret_cast<const f32x4_t*>(a.slope + cq);
+        if (cq + 16 < a.Cout) s1 = *reinterpret_cast<const f32x4_t*>(a.slope + cq + 16);
+      }
       const int c = n0 + wn * WTN + (j + (fgrp & 1)) * 16 + (fgrp >> 1) * 8;  // the 8 channels it stores
       int sg = 0;
 #pragma unroll
@@ -534,6 +539,13 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_wsp_kernel(cons
         if (relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+        }
+        if (prelu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v0[e] = v0[e] > 0.f ? v0[e] : v0[e] * s0[e];
+            v1[e] = v1[e] > 0.f ? v1[e] : v1[e] * s1[e];
+          }
         }
         const int m = m0 + wm * WTM + i * 16 + frow;
         if constexpr (is_planar<T>::value) {
@@ -633,7 +645,7 @@ static int cu_count() {
 // the persistent form (bias + ReLU layers of the 2-byte plans; VNF_WS_PERSIST=0 keeps one tile per workgroup)
 static bool ws_persistent(const KArgs& k) {
   static const bool on = !(getenv("VNF_WS_PERSIST") && atoi(getenv("VNF_WS_PERSIST")) == 0);
-  return on && k.ncls == 1 && !k.out_f32 && k.act != ACT_PRELU;
+  return on && k.ncls == 1 && !k.out_f32;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int S, int LW, bool RES>
