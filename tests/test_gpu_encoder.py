@@ -400,3 +400,29 @@ def test_fused_stem_split_f16_matches_the_plan_and_the_oracle(irv1_sd, monkeypat
     ref = irv1.irv1_forward(irv1_sd, x[:k], taps=taps).numpy()
     assert np.abs(tf_[:k] - taps["conv2d_3b"].numpy()).max() / scale <= 1e-5
     assert np.linalg.norm(yf[:k] - ref, axis=1).max() <= 1e-4
+
+
+@pytest.mark.parametrize("arch,dt", [("irv1", "bf16"), ("irv1", "f16"), ("irv1", "f16x2"), ("ir100", "bf16")])
+def test_persistent_conv_kernel_is_bitwise_the_one_tile_kernel(monkeypatch, arch, dt):
+    """conv_ws.hip's persistent form (a workgroup walks several output tiles, loaders run the ring across tile
+    boundaries, accumulators leave through a register epilogue: lane-row swaps -> 16-byte stores, residual chunks
+    fetched at tile start, PReLU slopes beside the bias) against one tile per workgroup with the LDS-staged epilogue
+    (VNF_WS_PERSIST=0), on the per-convolution plan (VNF_FUSE=0) so every layer shape of the network goes through a
+    convolution kernel: same K order, sums and roundings, so the embeddings must be bit for bit the same -- ragged last
+    tiles, tiles that cross image boundaries and the residual / PReLU layers (Block8 / Block17 / Block35 up
+    projections, IR-100 units) included."""
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1, iresnet100
+    n, size = (131, 160) if arch == "irv1" else (9, 112)
+    x = seeded_normal((n, 3, size, size), 91).cuda()
+    monkeypatch.setenv("VNF_FUSE", "0")
+
+    def build():
+        if arch == "irv1":
+            return InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=n).eval()
+        return iresnet100(pretrained=False, compute_dtype=dt, max_batch=n).to("cuda:0").eval()
+
+    ya = build()(x)                              # autotuned with the persistent form available
+    monkeypatch.setenv("VNF_WS_PERSIST", "0")
+    yb = build()(x)                              # autotuned again: other tile choices, same arithmetic
+    assert torch.isfinite(ya).all()
+    assert torch.equal(ya, yb)

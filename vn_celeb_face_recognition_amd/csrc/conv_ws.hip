@@ -644,8 +644,8 @@ static int cu_count() {
 
 // the persistent form (bias + ReLU layers of the 2-byte plans; VNF_WS_PERSIST=0 keeps one tile per workgroup)
 static bool ws_persistent(const KArgs& k) {
-  static const bool on = !(getenv("VNF_WS_PERSIST") && atoi(getenv("VNF_WS_PERSIST")) == 0);
-  return on && k.ncls == 1 && !k.out_f32;
+  const char* e = getenv("VNF_WS_PERSIST");   // read per launch: the parity test flips it inside one process
+  return !(e && atoi(e) == 0) && k.ncls == 1 && !k.out_f32;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int S, int LW, bool RES>
