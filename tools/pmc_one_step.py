@@ -22,12 +22,12 @@ if os.environ.get("VNF_PRINT_PLAN"):
         mm = re.search(r"([0-9.]+) ms\s+([0-9.]+) GFLOP", line)
         gf = float(mm.group(2)) if mm else 0.0
         label = line[:28].strip() or line.split()[0]
-        launches = 5 if "fused blocks" in line else 1
+        launches = 5 if ("fused blocks" in line and "one launch per block" in line) else 1   # the stack kernel: one launch
         print("PLAN %d %.3f %s" % (launches, gf, label), flush=True)
         if label.startswith("conv2d_4b"):
             # the ops up to here form the stem group, which the engine runs once per sub-batch (engine.cpp groups:
             # 128 images unfused, the whole batch when conv2d_2a/2b/maxpool are fused)
-            fuse = int(os.environ.get("VNF_FUSE", "15"))
+            fuse = int(os.environ.get("VNF_FUSE", "31"))
             fused_stem = (DT in ("bf16", "f16") and (fuse & 4)) or (DT == "f16x2" and (fuse & 12) == 12)
             chunk = int(os.environ.get("VNF_STEM_CHUNK", "256" if fused_stem else "128"))
             print("GROUP_END %d" % ((bs + chunk - 1) // chunk), flush=True)
