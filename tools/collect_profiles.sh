@@ -37,8 +37,8 @@ cp $OUT/${R}_traffic.json $ROOT/profiles/${R}_traffic.json   # bench.py quotes i
 python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err || exit 1
 python bench.py --workload detect --detectors 2 > $OUT/${R}_bench_detect.json 2>/dev/null || exit 1
 python bench.py --workload embed --model ir100 --no-cpu-baseline > $OUT/${R}_bench_ir100.json 2>/dev/null || exit 1
-python tools/profile_encoder.py 256 bf16 > $OUT/${R}_irv1_bs256_bf16_layer_times.txt 2>/dev/null || exit 1
-python tools/run_layers.py f16x2 > $OUT/${R}_irv1_bs256_f16x2_layer_times.txt 2>/dev/null || exit 1
+python tools/run_layers.py bf16 2>/dev/null | grep -av amdgpu.ids > $OUT/${R}_irv1_bs256_bf16_layer_times.txt || exit 1   # one lane, no internal half-batch forks
+python tools/run_layers.py f16x2 2>/dev/null | grep -av amdgpu.ids > $OUT/${R}_irv1_bs256_f16x2_layer_times.txt || exit 1
 python bench.py --workload stream --dtype f16x2 --no-cpu-baseline > $OUT/${R}_bench_stream_f16x2.json 2>/dev/null || exit 1
 python bench.py --workload pipeline --detectors 2 --no-cpu-baseline > $OUT/${R}_bench_pipeline_2handles.json 2>/dev/null || exit 1
 # 3b. detector stage / layer tables (MTCNN cascade on 16 x 1080p; RetinaFace swap-in detector)
