@@ -1,5 +1,6 @@
 // HBM-bound helper kernels around the convolution core: layout packing, pooling, L2 norm.
 // All are coalesced streaming kernels (16-byte accesses along the NHWC channel axis).
+#include <cstdlib>
 #include <algorithm>
 #include "kernels.h"
 #include "split_f16.h"
@@ -133,8 +134,103 @@ __global__ void __launch_bounds__(256) stem_conv1a_kernel(const TI* __restrict__
   }
 }
 
+// The same convolution on the f32 MFMA (v_mfma_f32_16x16x4_f32: the f32 vector rate, exact fmaf chain in k order, so
+// bit-identical to the kernel above), for the 16-bit and planar split-f16 plans.  The VALU form reads its 27 x 32 weights
+// as wave-uniform scalars at every tap -- 864 values do not fit the SGPR file, and the refetch, not the FMAs, set its
+// time in the split-f16 plan (0.098 -> 0.07 ms; bf16: 0.062 -> 0.059, where the rest is index arithmetic and the two
+// memory streams).  Here the weights are the A operand: lane (row r, k slot g) keeps
+// w[k = 4t + g][channel 16 ct + r] for the 7 k-steps and both channel tiles in 14 VGPRs, loaded once; B = 16 output
+// pixels, lane (pixel, g) fetching tap k = 4t + g of its pixel; D = channels 4g .. 4g+3 of the pixel per tile.  A lane-row
+// swap between the two tiles gives every lane 8 channels = one 16-byte store (planar: one hi and one lo chunk).
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) stem_conv1a_mfma_kernel(const TI* __restrict__ x, TO* __restrict__ y, int ldy, int n,
+                                                               const float* __restrict__ wt) {
+  constexpr int S = 160, SO = 79, NPX = SO * SO, G = 4;   // G pixel groups of 16 per wave iteration
+  const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
+  const unsigned total = (unsigned)n * NPX;
+  const unsigned ngroups = (total + 15) / 16;
+  const unsigned nwaves = gridDim.x * 4, w0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  float wa[2][7], bias[2][4];
+  int koff[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int k = 4 * t + g;
+    wa[0][t] = k < 27 ? wt[k * 32 + col] : 0.f;
+    wa[1][t] = k < 27 ? wt[k * 32 + 16 + col] : 0.f;
+    koff[t] = k < 27 ? (k / 9) * S * S + ((k % 9) / 3) * S + k % 3 : 0;
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias[ct][e] = wt[27 * 32 + 16 * ct + 4 * g + e];
+  const int cst = (g & 1) * 16 + (g >> 1) * 8;   // the 8 channels this lane stores after the swap
+  for (unsigned gi = w0 * G; gi < ngroups; gi += nwaves * G) {
+    float xb[G][7];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const unsigned i = min((gi + q) * 16 + col, total - 1);
+      const unsigned img = i / NPX, p = i - img * NPX;
+      const int oy = (int)(p / SO), ox = (int)(p - (unsigned)oy * SO);
+      const TI* src = x + (size_t)img * 3 * S * S + (size_t)(2 * oy) * S + 2 * ox;
+#pragma unroll
+      for (int t = 0; t < 7; ++t) xb[q][t] = to_f(src[koff[t]]);
+    }
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4 a0 = {bias[0][0], bias[0][1], bias[0][2], bias[0][3]}, a1 = {bias[1][0], bias[1][1], bias[1][2], bias[1][3]};
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][t], xb[q][t], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][t], xb[q][t], a1, 0, 0, 0);
+      }
+      const unsigned i = (gi + q) * 16 + col;
+      const bool ok = gi + q < ngroups && i < total;
+      if constexpr (__is_same(TO, pf16)) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 h0, l0, h1, l1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const sf16 s0(fmaxf(a0[e], 0.f)), s1(fmaxf(a1[e], 0.f));
+          h0[e] = s0.hi; l0[e] = s0.lo;
+          h1[e] = s1.hi; l1[e] = s1.lo;
+        }
+        const uint2 ph0 = __builtin_bit_cast(uint2, h0), ph1 = __builtin_bit_cast(uint2, h1);
+        const uint2 pl0 = __builtin_bit_cast(uint2, l0), pl1 = __builtin_bit_cast(uint2, l1);
+        const auto hx = __builtin_amdgcn_permlane16_swap(ph0.x, ph1.x, false, false);
+        const auto hy = __builtin_amdgcn_permlane16_swap(ph0.y, ph1.y, false, false);
+        const auto lx = __builtin_amdgcn_permlane16_swap(pl0.x, pl1.x, false, false);
+        const auto ly = __builtin_amdgcn_permlane16_swap(pl0.y, pl1.y, false, false);
+        if (ok) {
+          char* d = reinterpret_cast<char*>(y) + ((size_t)i * ldy + cst) * 4;
+          *reinterpret_cast<uint4*>(d) = uint4{hx[0], hy[0], hx[1], hy[1]};
+          *reinterpret_cast<uint4*>(d + 16) = uint4{lx[0], ly[0], lx[1], ly[1]};
+        }
+      } else {
+        typedef TO t4 __attribute__((ext_vector_type(4)));
+        t4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o0[e] = (TO)fmaxf(a0[e], 0.f); o1[e] = (TO)fmaxf(a1[e], 0.f); }
+        const uint2 p0 = __builtin_bit_cast(uint2, o0), p1 = __builtin_bit_cast(uint2, o1);
+        const auto sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+        if (ok) *reinterpret_cast<uint4*>(y + (size_t)i * ldy + cst) = uint4{sx[0], sy[0], sx[1], sy[1]};
+      }
+    }
+  }
+}
+
 template <typename TI>
 static hipError_t stem_dispatch_out(const void* x, void* y, int ldy, int dtype, int n, const float* wt, hipStream_t s) {
+  static const bool mfma = !(getenv("VNF_STEM1A_MFMA") && atoi(getenv("VNF_STEM1A_MFMA")) == 0);
+  if (mfma && n > 0 && (dtype == BF16 || dtype == F16 || dtype == F16P)) {
+    const unsigned ngroups = ((unsigned)n * 79 * 79 + 15) / 16;
+    const int blocks = (int)((ngroups + 15) / 16 < 2048 ? (ngroups + 15) / 16 : 2048);   // 4 waves x 4 groups per block round
+    if (dtype == BF16) hipLaunchKernelGGL((stem_conv1a_mfma_kernel<TI, __bf16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (__bf16*)y, ldy, n, wt);
+    else if (dtype == F16) hipLaunchKernelGGL((stem_conv1a_mfma_kernel<TI, _Float16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (_Float16*)y, ldy, n, wt);
+    else hipLaunchKernelGGL((stem_conv1a_mfma_kernel<TI, pf16>), dim3(blocks), dim3(256), 0, s, (const TI*)x, (pf16*)y, ldy, n, wt);
+    return hipGetLastError();
+  }
   const unsigned total = (unsigned)n * 79 * 79;
   const int blocks = (int)((total + 255) / 256);
   if (blocks == 0) return hipSuccess;
