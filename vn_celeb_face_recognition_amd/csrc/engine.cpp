@@ -1523,7 +1523,7 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
       } else if (op.kind == Op::STEM1) {
         const double gf = 2.0 * convs[op.a].macs_alg * n / 1e9;
         snprintf(line, sizeof line, "%-28s %-60s %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n", "conv2d_1a (direct, NCHW in)",
-                 "3x3 s2 3->32 on the caller's tensor, VALU packed FMA", ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
+                 "3x3 s2 3->32 on the caller's tensor, exact f32 (MFMA / VALU)", ms[oi], gf, ms[oi] > 0 ? gf / ms[oi] : 0.0);
       } else {
         static const char* kn[] = {"pack", "conv", "maxpool", "avgpool", "l2norm", "copyout", "maxpool_ceil", "stem1", "dwconv3x3",
                                    "upsample_add", "retina_stem (u8 frames -> conv0)", "dw3x3+pw1x1 fused"};
