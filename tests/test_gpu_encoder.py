@@ -254,7 +254,7 @@ def test_persistent_block17_trunk_kernel_matches_the_unfused_plan_and_the_oracle
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("n", [1, 7])
-@pytest.mark.parametrize("fuse", ["2", "18"])
+@pytest.mark.parametrize("fuse", ["2", "18", "50"])
 def test_fused_block35_is_bitwise_the_five_launch_plan(monkeypatch, dt, n, fuse):
     """repeat_1 (5 x Block35, inception_resnet_v1.py:36-67): one fused launch per block (block35.hip: all intermediates in
     LDS, pixel tiles split over the waves, weights in MFMA fragment order) -- or, VNF_FUSE bit 4, ONE launch for the five
@@ -264,7 +264,7 @@ def test_fused_block35_is_bitwise_the_five_launch_plan(monkeypatch, dt, n, fuse)
     of the 19th tile and every batch position included."""
     from vn_celeb_face_recognition_amd.models import InceptionResnetV1
     x = seeded_normal((n, 3, 160, 160), 57 + n).cuda()
-    monkeypatch.setenv("VNF_FUSE", fuse)     # Block35 only: per block (2) / the stack in one launch (18)
+    monkeypatch.setenv("VNF_FUSE", fuse)     # Block35 only: per block (2) / the stack in one launch (18) / + mixed_6a.branch1.0 (50)
     fused = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=n).eval()
     yf = fused(x)
     a4, r1 = fused.tap("conv2d_4b", n), fused.tap("repeat_1", n)
@@ -276,6 +276,8 @@ def test_fused_block35_is_bitwise_the_five_launch_plan(monkeypatch, dt, n, fuse)
     assert np.isfinite(r1).all()
     bad = np.argwhere(r1 != want)
     assert len(bad) == 0, (len(bad), bad[:8], r1[tuple(bad[0])], want[tuple(bad[0])])
+    # mixed_6a (whose branch1.0 the stack kernel computes from its registers under bit 5) and the embeddings
+    assert np.array_equal(fused.tap("mixed_6a", n), plain.tap("mixed_6a", n))
     assert torch.equal(yf, yp)
 
 

@@ -40,9 +40,16 @@ struct Block35StackArgs {
   void* y;            // (n, 289, ldy) output of the last block (may alias x)
   int ldx, ldy, n, nblocks;
   const void* wimg;   // nblocks block35_repack images, B35_WIMG_BYTES apart
+  // optional: mixed_6a.branch1.0 (1x1, 256 -> 192, folded BN, ReLU: inception_resnet_v1.py:137) on the stack's output while it
+  // is still in registers: wtail = block35_tail_repack image, ytail = (n, 289, ldyt) output; nullptr: no fusion
+  const void* wtail = nullptr;
+  void* ytail = nullptr;
+  int ldyt = 0;
   long long* dbg = nullptr;  // in-kernel stamp buffer of the instrumented launch (tools), else null
 };
 hipError_t launch_block35_stack(const Block35StackArgs& a, int dtype, hipStream_t s);
+constexpr int B35_TAIL_BYTES = 97 * 1024;   // 96 weight fragments (k-step x 12 channel tiles) + 1 KiB of fp32 biases
+hipError_t block35_tail_repack(const void* w, int kpad, const float* bias, void* out, hipStream_t s);
 const char* conv_zero_page();  // conv_igemm.hip: per-device page of zero bytes
 
 }  // namespace vnf

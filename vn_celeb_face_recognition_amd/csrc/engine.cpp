@@ -279,7 +279,8 @@ int Encoder::finalize() {
 // plan already uploaded (same folding, same k order), biases are concatenated per block.
 int Encoder::prepare_fused() {
   // bit 0: Block17 stack, bit 1: Block35, bit 2: stem 2a+2b+pool, bit 3: conv2d_3b inside the stem kernel, bit 4: the five
-  // Block35 in one launch (with bit 1); read at create time
+  // Block35 in one launch (with bit 1), bit 5 (off by default: measured at parity with the separate launch):
+  // mixed_6a.branch1.0 inside that launch; read at create time
   const int enabled = getenv("VNF_FUSE") ? atoi(getenv("VNF_FUSE")) : 31;
   for (FusedStack& f : fused) {
     f.active = false;
@@ -339,6 +340,22 @@ int Encoder::prepare_fused() {
       VNF_HIP(hipDeviceSynchronize());
       f.active = true;
       f.stack = (enabled & 16) && dtype != F16P;
+      f.ext = false;
+      if (f.stack && (enabled & 32) && f.ext_conv >= 0) {
+        const ConvLayer& t = convs[f.ext_conv];
+        const ConvLayer& last_up = convs[f.conv0 + 5 * (f.nblocks - 1) + 4];
+        const bool ok = t.KH == 1 && t.KW == 1 && t.K == 256 && t.cout == 192 && t.ncls == 1 && t.nseg == 1 && t.res_buf < 0 &&
+                        t.act == ACT_RELU && !t.out_f32 && t.x_buf == last_up.seg[0].buf && t.x_coff == 0 &&
+                        t.seg[0].buf == f.ext_out_buf && t.seg[0].coff == 0 && bufs[f.ext_out_buf].C == 192;
+        if (ok) {
+          f.wtail = dalloc(B35_TAIL_BYTES);
+          if (!f.wtail) return VNF_E_HIP;
+          VNF_HIP(block35_tail_repack(t.w, t.Kpad, t.bias, f.wtail, 0));
+          VNF_HIP(hipDeviceSynchronize());
+          f.ext = true;
+          f.macs_alg += t.macs_alg;
+        }
+      }
       continue;
     }
     if (!(enabled & 1)) continue;
@@ -388,7 +405,10 @@ bool Encoder::buf_materialised(int buf) const {
     bool produced = false;
     if (f.kind == 2) produced = buf == (f.ext ? f.ext_out_buf : f.out_buf);
     else if (f.kind == 35)
+    {
       for (int b = 0; b < f.nblocks; ++b) produced |= convs[f.conv0 + 5 * b + 4].seg[0].buf == buf;
+      produced |= f.ext && buf == f.ext_out_buf;
+    }
     else produced = buf == f.out_buf;
     if (!produced) return false;
   }
@@ -673,17 +693,19 @@ int build_irv1(Encoder& e, WeightMap& wm) {
   }
   e.taps["repeat_1"] = {x35[cur], 0, 256};
   {
-    FusedStack f;   // 16-bit compute dtypes: one fused launch per block (block35.hip)
+    FusedStack f;   // 16-bit compute dtypes: one fused launch per block (block35.hip) or for the whole stack (trunk35.hip)
     f.kind = 35;
     f.first = r1_first_op; f.last = (int)e.ops.size();
     f.nblocks = 5; f.conv0 = r1_first_conv;
+    // mixed_6a.branch1.0 (137) reads the stack's output only: listed right behind it so the stack kernel can take it over
+    TRY(simple("mixed_6a.branch1.0", x35[cur], 0, 256, 256, 192, 1, 1, 1, 0, 0, m6a, 0));
+    f.ext_last = (int)e.ops.size(); f.ext_conv = (int)e.convs.size() - 1; f.ext_out_buf = m6a;
     e.fused.push_back(f);
   }
   // ---- mixed_6a (129-149)
   {
     const int X = x35[cur], O = x17[0];
     TRY(simple("mixed_6a.branch0", X, 0, 256, 256, 384, 3, 3, 2, 0, 0, O, 0));
-    TRY(simple("mixed_6a.branch1.0", X, 0, 256, 256, 192, 1, 1, 1, 0, 0, m6a, 0));
     TRY(simple("mixed_6a.branch1.1", m6a, 0, 192, 192, 192, 3, 3, 1, 1, 1, m6b, 0));
     TRY(simple("mixed_6a.branch1.2", m6b, 0, 192, 192, 256, 3, 3, 2, 0, 0, O, 384));
     add_maxpool(e, X, O, 640);
@@ -1355,9 +1377,15 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
           ba.y = ob.ptr + (size_t)n0 * ob.elems_per_image() * es;
           ba.ldx = ib.C; ba.ldy = ob.C; ba.n = nn; ba.nblocks = fs->nblocks;
           ba.wimg = fs->wstream;
+          if (fs->ext) {
+            const Buf& tb = bufs[fs->ext_out_buf];
+            ba.wtail = fs->wtail;
+            ba.ytail = tb.ptr + (size_t)n0 * tb.elems_per_image() * es;
+            ba.ldyt = tb.C;
+          }
           hipError_t err = launch_block35_stack(ba, dtype, s);
           if (err != hipSuccess) return fail(VNF_E_HIP, std::string("fused Block35 stack: ") + hipGetErrorString(err));
-          oi = fs->last - 1;
+          oi = (fs->ext ? fs->ext_last : fs->last) - 1;
           continue;
         }
         if (fs && fs->kind == 35) {
@@ -1507,7 +1535,7 @@ int Encoder::run_range(const void* x, int i0, int i1, int x_dtype, float* out, h
         const double gf = 2.0 * fs->macs_alg * n / 1e9;
         snprintf(line, sizeof line, "%-28s %-60s %8.4f ms  %8.1f GFLOP %8.1f TFLOP/s\n",
                  fs->kind == 35 ? "repeat_1 (fused blocks)" : fs->kind == 2 ? (fs->ext ? "conv2d_2a+2b+maxpool_3a+3b" : "conv2d_2a+2b+maxpool_3a") : "repeat_2 (persistent trunk)",
-                 fs->kind == 35 ? (fs->stack ? "5 x Block35 in one launch, x in registers, one workgroup per image"
+                 fs->kind == 35 ? (fs->stack ? (fs->ext ? "5 x Block35 + mixed_6a.branch1.0 in one launch, x in registers" : "5 x Block35 in one launch, x in registers, one workgroup per image")
                                              : "5 x Block35, one launch per block, one workgroup per image")
                  : fs->kind == 2 ? "rolling rows, one launch, one workgroup per image"
                                  : "10 x Block17 in one launch, one workgroup per image",

@@ -100,10 +100,12 @@ struct FusedStack {
   int conv0 = 0;               // index of the first of the 4*nblocks convolutions (reduce, 1x7, 7x1, up per block)
   void* wstream = nullptr;
   float* bias = nullptr;
+  void* wtail = nullptr;       // kind 35 with ext: block35_tail_repack image of mixed_6a.branch1.0
   bool active = false;
   bool stack = false;          // kind 35: the five blocks in ONE launch, x resident in registers (trunk35.hip; bf16 / f16)
   double macs_alg = 0;         // per image
-  // kind 2 only: conv2d_3b (the op after the pool) folded into the stem kernel: ops [first, ext_last) become one launch
+  // kind 2: conv2d_3b (the op after the pool) folded into the stem kernel; kind 35 (stack): mixed_6a.branch1.0 (the op
+  // after the last block) computed from the register-resident output: ops [first, ext_last) become one launch
   int ext_last = 0, ext_conv = -1, ext_out_buf = -1;
   bool ext = false;
 };  // ops [first,last) run per `chunk` images (L3 residency)

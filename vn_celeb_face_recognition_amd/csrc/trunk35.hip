@@ -368,6 +368,71 @@ __device__ __forceinline__ void block35_stack_body(const Block35StackArgs& a, ch
   }
   wait_vm<0>();  // the redundant last prefetch: no DMA may be in flight into a workgroup's LDS when it ends
 
+  // ---- optional tail: mixed_6a.branch1.0 (1x1, 256 -> 192) on the stack's output, x still in registers: the reduce
+  // phase's machinery once more (fragments by lane-row swaps, weights in LDS in fragment order), three passes of four
+  // channel tiles, register epilogue with 16-byte stores.  Same K order, bias add, ReLU and rounding as the plan's
+  // convolution kernel: bit-identical to it.
+  if (a.wtail) {
+    using C13 = std::integral_constant<int, 13>;
+    __syncthreads();   // every wave's redundant last prefetch has landed (wait_vm<0> above): the regions may be refilled
+    copy_lin((const char*)a.wtail, 0, 97, C13{});   // 96 fragments over [0, 96 KiB), the biases behind them
+    wait_vm<0>();
+    __syncthreads();
+    int lane_t = lane_k;
+    asm volatile("" : "+v"(lane_t));
+    const int frow_t = lane_t & 15, fgrp_t = lane_t >> 4;
+    const float* tbias = reinterpret_cast<const float*>(smem + 96 * 1024);
+    char* __restrict__ yt = (char*)a.ytail + (size_t)img * NPX * a.ldyt * 2;
+#pragma unroll
+    for (int jh = 0; jh < 3; ++jh) {
+      f32x4_t acc[4][NT];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      // software-pipelined like phase A: k-step ks+1's fragments are fetched before k-step ks's MFMAs
+      uint4 xf[2][NT], wf[2][4];
+      auto fetch = [&](auto KS, auto C) {
+        constexpr int ks = decltype(KS)::value, c = decltype(C)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[c][j] = *reinterpret_cast<const uint4*>(smem + (ks * 12 + 4 * jh + j) * 1024 + lane_t * 16);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) xf[c][i] = quads_to_frag(xr[i][2 * ks], xr[i][2 * ks + 1]);
+      };
+      auto step = [&](auto KS) {
+        constexpr int ks = decltype(KS)::value, c = ks & 1;
+        if constexpr (ks + 1 < 8) fetch(std::integral_constant<int, ks + 1>{}, std::integral_constant<int, c ^ 1>{});
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < NT; ++i) acc[j][i] = Mma<T>::run(wf[c][j], xf[c][i], acc[j][i]);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+      step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const int t0 = 4 * jh + 2 * jp;   // channel tiles t0, t0 + 1 are exchanged between the lane rows
+        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(tbias + 16 * t0 + 4 * fgrp_t);
+        const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(tbias + 16 * t0 + 16 + 4 * fgrp_t);
+        const int c = (t0 + (fgrp_t & 1)) * 16 + (fgrp_t >> 1) * 8;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          f32x4_t v0 = acc[2 * jp][i], v1 = acc[2 * jp + 1][i];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e] + b0[e], 0.f); v1[e] = fmaxf(v1[e] + b1[e], 0.f); }
+          const uint2 p0 = pack4<T>(v0), p1 = pack4<T>(v1);
+          const auto sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+          const auto sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+          const int p = 16 * (wave + 8 * i) + frow_t;
+          if (p < NPX) *reinterpret_cast<uint4*>(yt + ((size_t)p * a.ldyt + c) * 2) = uint4{sx[0], sy[0], sx[1], sy[1]};
+        }
+      }
+    }
+  }
   if constexpr (DBG) {
     if (a.dbg && blockIdx.x == 100 && (threadIdx.x & 63) == 0) {
 #pragma unroll
@@ -430,6 +495,27 @@ static hipError_t launch_stack_stamped(const Block35StackArgs& a, hipStream_t s)
     fclose(f);
   }
   return hipSuccess;
+}
+
+// mixed_6a.branch1.0's packed engine weights [192 rows][kpad] -> 96 MFMA A-fragments (f = ks * 12 + j: rows 16 j .. + 15,
+// k = 32 ks + 8 (lane >> 4) .. + 7) and a last KiB with the 192 fp32 biases
+__global__ void block35_tail_repack_kernel(const char* __restrict__ w, int kpad, const float* __restrict__ bias, uint4* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int f = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (f > 96) return;
+  uint4 v = {0u, 0u, 0u, 0u};
+  if (f == 96) {
+    if (lane * 4 < 192) v = reinterpret_cast<const uint4*>(bias)[lane];
+  } else {
+    const int ks = f / 12, j = f % 12;
+    v = *reinterpret_cast<const uint4*>(w + ((size_t)(16 * j + (lane & 15)) * kpad + 32 * ks + 8 * (lane >> 4)) * 2);
+  }
+  out[(size_t)f * 64 + lane] = v;
+}
+
+hipError_t block35_tail_repack(const void* w, int kpad, const float* bias, void* out, hipStream_t s) {
+  hipLaunchKernelGGL(block35_tail_repack_kernel, dim3(25), dim3(256), 0, s, (const char*)w, kpad, bias, (uint4*)out);
+  return hipGetLastError();
 }
 
 hipError_t launch_block35_stack(const Block35StackArgs& a, int dtype, hipStream_t s) {
