@@ -363,7 +363,8 @@ __global__ __launch_bounds__((WM* WN + LW) * 64) void conv_igemm_wsp_kernel(cons
   // -------------------------------------------------------------------- consumer wave
   const int wm = wave / WN, wn = wave % WN;
   const int frow = lane & 15, fgrp = lane >> 4;
-  constexpr bool PIPE = (TM + TN) < 12;
+  // no staging epilogue here: the 4 x 8 wave tile double-buffers too (2-byte dtypes; the planar hi/lo sets would spill)
+  constexpr bool PIPE = (TM + TN) < 12 || ((TM + TN) == 12 && !is_planar<T>::value);
   constexpr int NF = PIPE ? 2 : 1;
   typedef typename std::conditional<is_planar<T>::value, _Float16, T>::type elem_t;
   typedef elem_t tx4 __attribute__((ext_vector_type(4)));
