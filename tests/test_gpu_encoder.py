@@ -428,3 +428,24 @@ def test_persistent_conv_kernel_is_bitwise_the_one_tile_kernel(monkeypatch, arch
     yb = build()(x)                              # autotuned again: other tile choices, same arithmetic
     assert torch.isfinite(ya).all()
     assert torch.equal(ya, yb)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16", "f16x2"])
+def test_conv2d_1a_on_the_f32_mfma_is_bitwise_the_valu_kernel(monkeypatch, dt):
+    """conv2d_1a (inception_resnet_v1.py:281, fp32 weights on the caller's NCHW tensor): the v_mfma_f32_16x16x4_f32
+    kernel (weights as the A operand, k = (c, kh, kw) in MFMA steps of four) against the packed-FMA VALU kernel
+    (VNF_STEM1A_MFMA=0): the f32 MFMA is an exact fmaf chain in k order, so the conv2d_1a tap and everything behind it
+    must be bit for bit the same -- odd batch, so the last 16-pixel group is ragged."""
+    from vn_celeb_face_recognition_amd.models import InceptionResnetV1
+    n = 5
+    x = seeded_normal((n, 3, 160, 160), 17).cuda()
+    monkeypatch.setenv("VNF_FUSE", "0")          # conv2d_1a readable as a tap, per-convolution plan behind it
+    m = InceptionResnetV1(pretrained=None, device="cuda:0", compute_dtype=dt, max_batch=n).eval()
+    ya = m(x)
+    ta = m.tap("conv2d_1a", n)
+    monkeypatch.setenv("VNF_STEM1A_MFMA", "0")
+    yb = m(x)
+    tb = m.tap("conv2d_1a", n)
+    assert np.isfinite(ta).all() and np.abs(ta).max() > 0
+    assert np.array_equal(ta, tb)
+    assert torch.equal(ya, yb)

@@ -222,7 +222,8 @@ __global__ void __launch_bounds__(256) stem_conv1a_mfma_kernel(const TI* __restr
 
 template <typename TI>
 static hipError_t stem_dispatch_out(const void* x, void* y, int ldy, int dtype, int n, const float* wt, hipStream_t s) {
-  static const bool mfma = !(getenv("VNF_STEM1A_MFMA") && atoi(getenv("VNF_STEM1A_MFMA")) == 0);
+  const char* e1a = getenv("VNF_STEM1A_MFMA");   // read per launch: the parity test flips it inside one process
+  const bool mfma = !(e1a && atoi(e1a) == 0);
   if (mfma && n > 0 && (dtype == BF16 || dtype == F16 || dtype == F16P)) {
     const unsigned ngroups = ((unsigned)n * 79 * 79 + 15) / 16;
     const int blocks = (int)((ngroups + 15) / 16 < 2048 ? (ngroups + 15) / 16 : 2048);   // 4 waves x 4 groups per block round
