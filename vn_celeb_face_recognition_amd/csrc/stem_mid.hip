@@ -123,13 +123,13 @@ __global__ __launch_bounds__(512, 2) void stem_mid_kernel(const StemMidArgs a) {
   }
 
   // 1a row r -> input ring slot r % 6: 5 pieces of 16 px x 64 B; lane -> (px = lane >> 2, physical slot = lane & 3), the
-  // swizzle rides on the source address.  Waves 6, 7 issue 3 pieces each (ids clamp: piece 4 is loaded twice).
+  // swizzle rides on the source address.  Wave 7 (the lightest: one 2a pixel tile, no pooling) issues all 5 pieces.
   auto issue_row = [&](int r) {
-    if (wave < 6) return;
+    if (wave != 7) return;
     const int rr = min(r, W1A - 1);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int id = min((wave - 6) * 3 + i, 4);
+    for (int i = 0; i < 5; ++i) {
+      const int id = i;
       const int p = id * 16 + (lane >> 2), slot = lane & 3;
       const int pc = min(p, W1A - 1);   // pixels 79..: inside the padding of the ring row, any finite data
       glds16(xg + ((size_t)(rr * W1A + pc) * a.ldx + ((slot ^ ((0 - (p >> 2)) & 3)) << 3)) * 2,
@@ -354,12 +354,22 @@ __global__ __launch_bounds__(512, 2) void stem_mid_kernel(const StemMidArgs a) {
       }
       // Row s+9 goes out now (its slot held row s-3, last read -- prefetched -- at the end of step s-4).  Row r is first
       // read at the end of step r-3 (the prefetch of step r-2's third filter row), after the barrier of step r-4, i.e.
-      // 5 steps after its issue; every step issues >= 3 memory operations per DMA wave, so "all but the 15 youngest
+      // 5 steps after its issue; every step issues >= 5 memory operations on the DMA wave, so "all but the 25 youngest
       // complete" at the end of each step retires every piece at least 5 steps old.
       if (s + AHEAD < W1A) issue_row(s + AHEAD);
       // next step's first two filter rows (complete since the previous barrier at the latest)
       prefetch(s + 1);
-      if (wave >= 6) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+      if (wave == 7) {
+        // ... and once the last row has gone out, the allowance shrinks by one row per step so that the guarantee
+        // ("every piece at least 5 steps old has landed") also holds for the image's last rows
+        const int j = s + AHEAD - (W1A - 1);   // steps since the last issue
+        if (j <= 0) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+        else if (j == 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else if (j == 2) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        else if (j == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (j == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       stamp(5);
       // The barrier needs this wave's LDS WRITES done, not the prefetch reads just issued behind them (LDS operations
       // retire in order): wait for all but the youngest KPF.  __syncthreads() would wait for lgkmcnt(0) and put the

@@ -311,7 +311,13 @@ __global__ __launch_bounds__(512, 2) void stem_mid_split_kernel(const StemMidArg
     // complete" at the end of each step retires every piece at least 2 steps old (the y stores of conv2d_3b in the window
     // only make the wait stricter).
     if (s + AHEAD < W1A) issue_row(s + AHEAD);
-    if (wave >= 6) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    if (wave >= 6) {
+      // once the last row has gone out the allowance shrinks with it, so the image's last rows are covered as well
+      const int j = s + AHEAD - (W1A - 1);   // steps since the last issue
+      if (j <= 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (j == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
   }
 }
