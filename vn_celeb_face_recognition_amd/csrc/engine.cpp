@@ -1030,7 +1030,9 @@ static void add_pool_ceil(Encoder& e, int ib, int ob, int k) {
 
 // front == true: conv1 + PReLU + pool1 are computed by the detector's own fused kernel (mtcnn.hip net_front_kernel),
 // which reads buffer 0 (the crops) and writes buffer 1 (the pooled map); the plan starts at conv2.
-int build_rnet(Encoder& e, WeightMap& wm, bool front) {
+// front: conv1 + pool1 come from net_front_kernel (the plan starts at conv2); mid: conv2 + pool2 as well, from
+// net_mid_kernel (mtcnn.hip: the plan starts at conv3 and reads buffer 3)
+int build_rnet(Encoder& e, WeightMap& wm, bool front, bool mid) {
   e.in_size = 24;
   const int in = e.add_buf(24, 24, 4), p1 = e.add_buf(11, 11, 32);
   const int c2 = e.add_buf(9, 9, 48), p2 = e.add_buf(4, 4, 48), c3 = e.add_buf(3, 3, 64), d4 = e.add_buf(1, 1, 128);
@@ -1041,15 +1043,17 @@ int build_rnet(Encoder& e, WeightMap& wm, bool front) {
     TRY(mtcnn_conv(e, wm, "conv1", "prelu1", in, 3, 4, 28, 32, 3, c1));
     add_pool_ceil(e, c1, p1, 3);
   }
-  TRY(mtcnn_conv(e, wm, "conv2", "prelu2", p1, 28, 32, 48, 48, 3, c2));
-  add_pool_ceil(e, c2, p2, 3);
+  if (!mid) {
+    TRY(mtcnn_conv(e, wm, "conv2", "prelu2", p1, 28, 32, 48, 48, 3, c2));
+    add_pool_ceil(e, c2, p2, 3);
+  }
   TRY(mtcnn_conv(e, wm, "conv3", "prelu3", p2, 48, 48, 64, 64, 2, c3));
   TRY(mtcnn_dense(e, wm, "dense4", "prelu4", c3, 64, 128, d4, keep));
   TRY(mtcnn_heads(e, wm, {{"dense5_1", 2}, {"dense5_2", 4}}, d4, 128, hd, 8));
   return VNF_OK;
 }
 
-int build_onet(Encoder& e, WeightMap& wm, bool front) {
+int build_onet(Encoder& e, WeightMap& wm, bool front, bool mid) {
   e.in_size = 48;
   const int in = e.add_buf(48, 48, 4), p1 = e.add_buf(23, 23, 32);
   const int c2 = e.add_buf(21, 21, 64), p2 = e.add_buf(10, 10, 64), c3 = e.add_buf(8, 8, 64), p3 = e.add_buf(4, 4, 64);
@@ -1061,8 +1065,10 @@ int build_onet(Encoder& e, WeightMap& wm, bool front) {
     TRY(mtcnn_conv(e, wm, "conv1", "prelu1", in, 3, 4, 32, 32, 3, c1));
     add_pool_ceil(e, c1, p1, 3);
   }
-  TRY(mtcnn_conv(e, wm, "conv2", "prelu2", p1, 32, 32, 64, 64, 3, c2));
-  add_pool_ceil(e, c2, p2, 3);
+  if (!mid) {
+    TRY(mtcnn_conv(e, wm, "conv2", "prelu2", p1, 32, 32, 64, 64, 3, c2));
+    add_pool_ceil(e, c2, p2, 3);
+  }
   TRY(mtcnn_conv(e, wm, "conv3", "prelu3", p2, 64, 64, 64, 64, 3, c3));
   add_pool_ceil(e, c3, p3, 2);
   TRY(mtcnn_conv(e, wm, "conv4", "prelu4", p3, 64, 64, 128, 128, 2, c4));

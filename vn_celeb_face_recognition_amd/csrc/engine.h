@@ -159,7 +159,7 @@ int build_ir100(Encoder& e, WeightMap& wm);
 // RetinaFace (mobilenet0.25) on the exact-f32 core for an H x W input: buffer 0 = NHWC4 mean-subtracted input (written by
 // the caller), head_bufs[l] = (Hl, Wl, 32) fp32 [cls 4 | bbox 8 | landmark 20] of pyramid level l
 int build_retina_mnet(Encoder& e, WeightMap& wm, int H, int W, int head_bufs[3]);
-int build_rnet(Encoder& e, WeightMap& wm, bool front = false);
-int build_onet(Encoder& e, WeightMap& wm, bool front = false);
+int build_rnet(Encoder& e, WeightMap& wm, bool front = false, bool mid = false);
+int build_onet(Encoder& e, WeightMap& wm, bool front = false, bool mid = false);
 
 }  // namespace vnf

@@ -1001,6 +1001,98 @@ __global__ void __launch_bounds__(NT) net_front_kernel(const float* __restrict__
   }
 }
 
+// --------------------------------------------------------------------------------------------- K6b
+// R-Net / O-Net conv2 (32 -> 48 / 64, 3x3) + PReLU + MaxPool(3, 2, ceil_mode) in one kernel (mtcnn.py:88-90 / 142-144)
+// for the split-f16 plans: one workgroup per candidate, the pooled conv1 map (net_front_kernel's output: [pixel][32
+// channels] of (hi, lo) pairs) in LDS, the convolution as 16x16x32 f16 MFMAs on the interleaved split operands -- per
+// 16 k values (one tap, 16 channels) the chunk pair and the pair with the activation's halves swapped, exactly
+// mma_chunk<sf16>, in the plan's k order (tap-major) with its fp32 sum, bias and PReLU -- weights as 18 A-fragments per
+// 16-channel tile in REGISTERS, the conv map ([pixel][channels of the pass] fp32) only ever in LDS, pooled from there
+// and written as split-f16 NHWC rows for the plan's conv3.  The unfused plan wrote and re-read that map (O-Net: 99 MB
+// per 880 candidates) and paid two launches: 0.089 + 0.029 ms (O-Net), 0.057 + 0.017 ms (R-Net) per 16 frames.
+typedef _Float16 f16x8m_t __attribute__((ext_vector_type(8)));
+struct MidW { const uint4* w; const float* b; const float* a; };   // [CO/16][18][64 lanes] fragments, [CO], [CO]
+
+template <int PI, int CO, int NWAVE, int NPASS>
+__global__ void __launch_bounds__(NWAVE * 64) net_mid_kernel(const float* __restrict__ p1, MidW mw, float* __restrict__ p2) {
+  constexpr int C = PI - 2, NPX = C * C, PO = (C - 3 + 1) / 2 + 1;
+  constexpr int NCT = CO / 16, CTP = NCT / NPASS, NMG = NWAVE / CTP, NMT = (NPX + 15) / 16;
+  constexpr int CHP = CTP * 4;   // 16-byte fp32 chunks per conv pixel in one pass
+  static_assert(NCT % NPASS == 0 && NWAVE % CTP == 0, "channel tiles divide over passes and waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* s_in = reinterpret_cast<uint4*>(smem);                       // [PI * PI][8 chunks of 4 (hi, lo) channels], chunk ^ (px & 7)
+  float4* s_cv = reinterpret_cast<float4*>(smem + PI * PI * 128);    // [NPX][CHP]
+  const int cand = blockIdx.x, t = threadIdx.x;
+  const int wave = t >> 6, lane = t & 63, frow = lane & 15, g = lane >> 4;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(p1) + (size_t)cand * PI * PI * 8;
+    for (int i = t; i < PI * PI * 8; i += NWAVE * 64) {
+      const int q = i >> 3, ch = i & 7;
+      s_in[q * 8 + (ch ^ (q & 7))] = src[i];
+    }
+  }
+  __syncthreads();
+  const int ctl = wave % CTP, mg = wave / CTP;
+#pragma unroll 1
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const int ct = pass * CTP + ctl;
+    uint4 wf[18];
+#pragma unroll
+    for (int kb = 0; kb < 18; ++kb) wf[kb] = mw.w[((size_t)ct * 18 + kb) * 64 + lane];
+    float bias[4], slope[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bias[e] = mw.b[ct * 16 + 4 * g + e]; slope[e] = mw.a[ct * 16 + 4 * g + e]; }
+    for (int tile = mg; tile < NMT; tile += NMG) {
+      const int px = tile * 16 + frow, pxc = min(px, NPX - 1);
+      const int oy = pxc / C, ox = pxc - oy * C;
+      const int q0 = oy * PI + ox;
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int q = q0 + (tap / 3) * PI + tap % 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint4 xf = s_in[q * 8 + ((4 * h + g) ^ (q & 7))];
+          const uint4 xr = {(xf.x >> 16) | (xf.x << 16), (xf.y >> 16) | (xf.y << 16), (xf.z >> 16) | (xf.z << 16),
+                            (xf.w >> 16) | (xf.w << 16)};
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8m_t, wf[2 * tap + h]),
+                                                       __builtin_bit_cast(f16x8m_t, xf), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8m_t, wf[2 * tap + h]),
+                                                       __builtin_bit_cast(f16x8m_t, xr), acc, 0, 0, 0);
+        }
+      }
+      if (px < NPX) {
+        float4 o;
+        float* op = reinterpret_cast<float*>(&o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[e] + bias[e];
+          op[e] = v > 0.f ? v : v * slope[e];
+        }
+        s_cv[px * CHP + ctl * 4 + g] = o;
+      }
+    }
+    __syncthreads();
+    float4* dst = reinterpret_cast<float4*>(p2) + (size_t)cand * PO * PO * (CO / 4) + pass * CHP;
+    for (int i = t; i < PO * PO * CHP; i += NWAVE * 64) {
+      const int chunk = i % CHP, pp = i / CHP, py = pp / PO, pxx = pp - py * PO;
+      float4 m = float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int rr = 2 * py + dy, xx = 2 * pxx + dx;
+          if (rr < C && xx < C) {
+            const float4 v = s_cv[(rr * C + xx) * CHP + chunk];
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+          }
+        }
+      dst[(size_t)pp * (CO / 4) + chunk] = float4{split_pack(m.x), split_pack(m.y), split_pack(m.z), split_pack(m.w)};
+    }
+    if (pass + 1 < NPASS) __syncthreads();
+  }
+}
+
 // --------------------------------------------------------------------------------------------- K6 building blocks
 // Direct convolution / pooling / dense layers over activations resident in LDS (CHW fp32),
 // weights in their PyTorch layout read through L1/L2 (shared by every workgroup).
@@ -1508,6 +1600,8 @@ struct Mtcnn : HandleBase {
   int pnet1_lds = 0;                          // dynamic LDS granted to pnet_conv1_pool_mfma_kernel
   bool front = false;                         // conv1 + PReLU + pool1 of both nets by net_front_kernel (plans start at conv2)
   FrontW rfw{}, ofw{};
+  bool mid = false;                           // conv2 + PReLU + pool2 by net_mid_kernel (split-f16 plans start at conv3)
+  MidW rmw{}, omw{};
   int r_cap = 0, o_cap = 0;
   int* offs = nullptr;                        // device: (max_batch + 1) compact-batch offsets
   // final read-back: counts block + the first FIN_FAST rows of every frame packed by one kernel into `stage`,
@@ -1687,13 +1781,45 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
           };
           if (!pack_front(wr, 28, m->rfw) || !pack_front(wo, 32, m->ofw)) { delete m; return fail(VNF_E_MISSING, "mtcnn: conv1 weights"); }
         }
-        int rr = build_rnet(*m->renc, wr, m->front);
+        static const bool mid_env = !getenv("VNF_MTCNN_MID") || atoi(getenv("VNF_MTCNN_MID")) != 0;
+        m->mid = mid_env && m->front && m->renc->dtype == F16X2;
+        if (m->mid) {
+          // conv2 weights [cout][cin][3][3] -> MFMA A-fragments of interleaved split-f16: fragment (ct, kb = 2 tap + half),
+          // lane (row r, group g) = the 4 k values (channels 16 half + 4 g .. + 3 of the tap) of output channel 16 ct + r
+          // as (hi, lo) pairs; input channels beyond cin (R-Net: 28 of 32) are zero
+          auto pack_mid = [&](WeightMap& wm, int cout, int cin, MidW& mw) -> bool {
+            const float* c2 = wm.get("conv2.weight", (int64_t)cout * cin * 9);
+            const float* b2 = wm.get("conv2.bias", cout);
+            const float* a2 = wm.get("prelu2.weight", cout);
+            if (!c2 || !b2 || !a2) return false;
+            std::vector<uint32_t> w((size_t)(cout / 16) * 18 * 64 * 4, 0u);
+            for (int ct = 0; ct < cout / 16; ++ct)
+              for (int kb = 0; kb < 18; ++kb)
+                for (int l = 0; l < 64; ++l)
+                  for (int e = 0; e < 4; ++e) {
+                    const int co = 16 * ct + (l & 15), c = 16 * (kb & 1) + 4 * (l >> 4) + e, tap = kb >> 1;
+                    const float v = c < cin ? c2[((size_t)(co * cin + c) * 3 + tap / 3) * 3 + tap % 3] : 0.f;
+                    const sf16 sv(v);
+                    uint32_t bits;
+                    memcpy(&bits, &sv, 4);
+                    w[(((size_t)ct * 18 + kb) * 64 + l) * 4 + e] = bits;
+                  }
+            mw.w = (const uint4*)m->upload(w.data(), w.size() * 4);
+            mw.b = (const float*)m->upload(b2, (size_t)cout * 4);
+            mw.a = (const float*)m->upload(a2, (size_t)cout * 4);
+            return mw.w && mw.b && mw.a;
+          };
+          if (!pack_mid(wr, 48, 28, m->rmw) || !pack_mid(wo, 64, 32, m->omw)) { delete m; return fail(VNF_E_MISSING, "mtcnn: conv2 weights"); }
+          (void)hipFuncSetAttribute((const void*)net_mid_kernel<23, 64, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 23 * 23 * 128 + 21 * 21 * 8 * 16);
+          (void)hipGetLastError();
+        }
+        int rr = build_rnet(*m->renc, wr, m->front, m->mid);
         if (rr == VNF_OK) rr = m->renc->finalize();
         m->oenc = new Encoder();
         m->oenc->max_streams = 1;
         m->oenc->tune_batch = std::max(1, m->o_cap / 4);
         m->oenc->kind = 1; m->oenc->arch = -3; m->oenc->dtype = m->renc->dtype; m->oenc->max_batch = m->o_cap;
-        if (rr == VNF_OK) rr = build_onet(*m->oenc, wo, m->front);
+        if (rr == VNF_OK) rr = build_onet(*m->oenc, wo, m->front, m->mid);
         if (rr == VNF_OK) rr = m->oenc->finalize();
         if (rr != VNF_OK) { delete m; return rr; }
       }
@@ -1923,6 +2049,11 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
         else if (split) hipLaunchKernelGGL((net_front_kernel<48, 4, 512, true>), dim3(6, n), dim3(512), lo, s, cin, m->ofw, pout);
         else hipLaunchKernelGGL((net_front_kernel<48, 4, 512, false>), dim3(6, n), dim3(512), lo, s, cin, m->ofw, pout);
         mark(S == 24 ? "rnet_front" : "onet_front", 0);
+        if (m->mid) {   // conv2 + PReLU + pool2: buffer 1 -> buffer 3 (the plan starts at conv3)
+          float* p2o = (float*)enc->bufs[3].ptr;
+          if (S == 24) hipLaunchKernelGGL((net_mid_kernel<11, 48, 6, 1>), dim3(n), dim3(384), 11 * 11 * 128 + 9 * 9 * 12 * 16, s, pout, m->rmw, p2o);
+          else hipLaunchKernelGGL((net_mid_kernel<23, 64, 8, 2>), dim3(n), dim3(512), 23 * 23 * 128 + 21 * 21 * 8 * 16, s, pout, m->omw, p2o);
+        }
       }
       static const bool layers = getenv("VNF_MTCNN_LAYERS") != nullptr;   // diagnostic: per-layer table on stderr
       std::string rep;
