@@ -1024,6 +1024,11 @@ __global__ void __launch_bounds__(NWAVE * 64) net_mid_kernel(const float* __rest
   float4* s_cv = reinterpret_cast<float4*>(smem + PI * PI * 128);    // [NPX][CHP]
   const int cand = blockIdx.x, t = threadIdx.x;
   const int wave = t >> 6, lane = t & 63, frow = lane & 15, g = lane >> 4;
+  const int ctl = wave % CTP, mg = wave / CTP;
+  // the first pass's weight fragments travel while the input map is copied to LDS; the next pass's while this one pools
+  uint4 wf[18];
+#pragma unroll
+  for (int kb = 0; kb < 18; ++kb) wf[kb] = mw.w[((size_t)ctl * 18 + kb) * 64 + lane];
   {
     const uint4* src = reinterpret_cast<const uint4*>(p1) + (size_t)cand * PI * PI * 8;
     for (int i = t; i < PI * PI * 8; i += NWAVE * 64) {
@@ -1032,13 +1037,9 @@ __global__ void __launch_bounds__(NWAVE * 64) net_mid_kernel(const float* __rest
     }
   }
   __syncthreads();
-  const int ctl = wave % CTP, mg = wave / CTP;
 #pragma unroll 1
   for (int pass = 0; pass < NPASS; ++pass) {
     const int ct = pass * CTP + ctl;
-    uint4 wf[18];
-#pragma unroll
-    for (int kb = 0; kb < 18; ++kb) wf[kb] = mw.w[((size_t)ct * 18 + kb) * 64 + lane];
     float bias[4], slope[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { bias[e] = mw.b[ct * 16 + 4 * g + e]; slope[e] = mw.a[ct * 16 + 4 * g + e]; }
@@ -1071,6 +1072,10 @@ __global__ void __launch_bounds__(NWAVE * 64) net_mid_kernel(const float* __rest
         }
         s_cv[px * CHP + ctl * 4 + g] = o;
       }
+    }
+    if (pass + 1 < NPASS) {
+#pragma unroll
+      for (int kb = 0; kb < 18; ++kb) wf[kb] = mw.w[((size_t)(ct + CTP) * 18 + kb) * 64 + lane];
     }
     __syncthreads();
     float4* dst = reinterpret_cast<float4*>(p2) + (size_t)cand * PO * PO * (CO / 4) + pass * CHP;
