@@ -362,3 +362,30 @@ def test_speculative_stage_sizing_is_exact_on_hits_and_misses(monkeypatch):
     for i in range(2):
         assert len(ob[i]) == len(first[0][i])
         assert np.abs(first[0][i] - np.asarray(ob[i]).reshape(-1, 4)).max() <= 1e-3
+
+
+def test_fused_conv2_pool_kernel_gives_the_plans_detections(monkeypatch):
+    """R-Net / O-Net conv2 + PReLU + ceil-mode pool (mtcnn.py:88-90, 142-144) in one kernel per candidate
+    (net_mid_kernel: the conv map only in LDS, the plan's split-f16 products in the plan's k order, pooled in fp32 and
+    split once) against the plan's conv2 and maxpool_ceil launches (VNF_MTCNN_MID=0), which split the conv map first and
+    pool the split values: the two differ by the split format's rounding (2^-22 relative) on the rare element where
+    that double rounding is not monotonic, so the detections must be the same faces with boxes within 1e-3 px,
+    probabilities within 1e-6 and landmarks within 1e-3 px -- on busy 1080p frames (hundreds of stage-2 candidates per
+    frame, ragged last tiles in both nets)."""
+    from vn_celeb_face_recognition_amd.models import MTCNN
+    from vn_celeb_face_recognition_amd.synth import make_frames
+    frames, _ = make_frames(3, 8, seed=21)
+
+    def run(det):
+        b, p, l = det.inference(list(frames), landmark=True)
+        return [np.asarray(x).reshape(-1, 4) for x in b], [np.asarray(x).reshape(-1) for x in p], [np.asarray(x).reshape(-1, 10) for x in l]
+
+    fused = run(MTCNN(keep_all=True, min_face_size=50, device="cuda:0", max_batch=3))
+    monkeypatch.setenv("VNF_MTCNN_MID", "0")
+    plain = run(MTCNN(keep_all=True, min_face_size=50, device="cuda:0", max_batch=3))
+    assert sum(len(x) for x in fused[0]) >= 18
+    for i in range(3):
+        assert fused[0][i].shape == plain[0][i].shape
+        assert np.abs(fused[0][i] - plain[0][i]).max() <= 1e-3
+        assert np.abs(fused[1][i] - plain[1][i]).max() <= 1e-6
+        assert np.abs(fused[2][i] - plain[2][i]).max() <= 1e-3

@@ -1008,7 +1008,8 @@ __global__ void __launch_bounds__(NT) net_front_kernel(const float* __restrict__
 // 16 k values (one tap, 16 channels) the chunk pair and the pair with the activation's halves swapped, exactly
 // mma_chunk<sf16>, in the plan's k order (tap-major) with its fp32 sum, bias and PReLU -- weights as 18 A-fragments per
 // 16-channel tile in REGISTERS, the conv map ([pixel][channels of the pass] fp32) only ever in LDS, pooled from there
-// and written as split-f16 NHWC rows for the plan's conv3.  The unfused plan wrote and re-read that map (O-Net: 99 MB
+// in fp32 and written as split-f16 NHWC rows for the plan's conv3 (the plan splits the map first and pools the split
+// values: the same up to the split format's 2^-22 rounding; detections agree to 1e-3 px / 1e-6, tested).  The unfused plan wrote and re-read that map (O-Net: 99 MB
 // per 880 candidates) and paid two launches: 0.089 + 0.029 ms (O-Net), 0.057 + 0.017 ms (R-Net) per 16 frames.
 typedef _Float16 f16x8m_t __attribute__((ext_vector_type(8)));
 struct MidW { const uint4* w; const float* b; const float* a; };   // [CO/16][18][64 lanes] fragments, [CO], [CO]
@@ -1786,7 +1787,7 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
           };
           if (!pack_front(wr, 28, m->rfw) || !pack_front(wo, 32, m->ofw)) { delete m; return fail(VNF_E_MISSING, "mtcnn: conv1 weights"); }
         }
-        static const bool mid_env = !getenv("VNF_MTCNN_MID") || atoi(getenv("VNF_MTCNN_MID")) != 0;
+        const bool mid_env = !getenv("VNF_MTCNN_MID") || atoi(getenv("VNF_MTCNN_MID")) != 0;   // read per handle
         m->mid = mid_env && m->front && m->renc->dtype == F16X2;
         if (m->mid) {
           // conv2 weights [cout][cin][3][3] -> MFMA A-fragments of interleaved split-f16: fragment (ct, kb = 2 tap + half),
