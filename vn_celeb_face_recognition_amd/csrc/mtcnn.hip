@@ -921,7 +921,11 @@ __device__ __forceinline__ float split_pack(float v) {
   const sf16 h(v);
   return __builtin_bit_cast(float, h);
 }
-template <int S, int BANDP, int NT, bool SPLIT>
+// MM16 (with SPLIT): conv1 itself on the 16-bit MFMA with split-f16 operands -- the crop pixels are split once when
+// they are copied to LDS (a pixel's 3 + 1 channels as four (hi, lo) pairs are the same 16 bytes as its four floats), a
+// k block is four taps x four channels, so the 9 taps are three MFMA pairs per 16-channel tile (96 cycles) instead of
+// nine f32 MFMAs (288); ~22 significant bits per operand like every later layer of the split plans.
+template <int S, int BANDP, int NT, bool SPLIT, bool MM16 = false>
 __global__ void __launch_bounds__(NT) net_front_kernel(const float* __restrict__ crops, FrontW fw, float* __restrict__ p1) {
   constexpr int C = S - 2;                 // conv1 rows / cols
   constexpr int P = (C - 3 + 1) / 2 + 1;   // ceil((C - 3) / 2) + 1
@@ -934,17 +938,35 @@ __global__ void __launch_bounds__(NT) net_front_kernel(const float* __restrict__
   const int p0 = band * BANDP, np = min(BANDP, P - p0);
   const int cr0 = 2 * p0, ncr = min(CR, C - cr0), nir = ncr + 2;
   const float4* src = reinterpret_cast<const float4*>(crops) + ((size_t)cand * S + cr0) * S;
-  for (int i = t; i < nir * S; i += NT) s_in[i] = src[i];
+  for (int i = t; i < nir * S; i += NT) {
+    float4 v = src[i];
+    if constexpr (MM16) v = float4{split_pack(v.x), split_pack(v.y), split_pack(v.z), split_pack(v.w)};
+    s_in[i] = v;
+  }
   __syncthreads();
   // conv1 as 16x16x4 fp32 MFMAs, one per (tap, 16-channel tile): A = weights (lane: channel l&15, input channel l>>4),
   // B = crop pixels (lane: pixel l&15, input channel l>>4; channel 3 is the zero pad), D = 4 consecutive output
   // channels of one pixel per lane.  Same k order as the plan's implicit-GEMM conv (tap-major), bias after the sum.
   const int wave = t >> 6, lane = t & 63, lg = lane >> 4, lm = lane & 15;
-  float wa[2][9];
+  float wa[2][MM16 ? 1 : 9];
+  uint4 ws[2][MM16 ? 3 : 1];   // MM16: A fragments, lane (channel lm, group lg) = tap 4 blk + lg, input channels 0..3 as (hi, lo) pairs
+  if constexpr (MM16) {
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) wa[ct][tap] = fw.w[((ct * 16 + lm) * 9 + tap) * 4 + lg];
+      for (int blk = 0; blk < 3; ++blk) {
+        const int tap = 4 * blk + lg;
+        float4 w4 = float4{0.f, 0.f, 0.f, 0.f};
+        if (tap < 9) w4 = *reinterpret_cast<const float4*>(fw.w + ((ct * 16 + lm) * 9 + tap) * 4);
+        const float4 sp = float4{split_pack(w4.x), split_pack(w4.y), split_pack(w4.z), split_pack(w4.w)};
+        ws[ct][blk] = __builtin_bit_cast(uint4, sp);
+      }
+  } else {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) wa[ct][tap] = fw.w[((ct * 16 + lm) * 9 + tap) * 4 + lg];
+  }
   float bias[2][4], slope[2][4];
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)
@@ -955,16 +977,34 @@ __global__ void __launch_bounds__(NT) net_front_kernel(const float* __restrict__
   for (int tile = wave; tile * 16 < npx; tile += NT / 64) {
     const int px = tile * 16 + lm, pxc = min(px, npx - 1);
     const int r = pxc / C, x = pxc - r * C;
-    float xb[9];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) xb[kh * 3 + kw] = s_inf[((r + kh) * S + x + kw) * 4 + lg];
     f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    if constexpr (MM16) {
+      typedef _Float16 f16x8f_t __attribute__((ext_vector_type(8)));
+      const uint4* s_inu = reinterpret_cast<const uint4*>(s_in);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][tap], xb[tap], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][tap], xb[tap], acc[1], 0, 0, 0);
+      for (int blk = 0; blk < 3; ++blk) {
+        const int tap = 4 * blk + lg;
+        uint4 xf = uint4{0u, 0u, 0u, 0u};
+        if (tap < 9) xf = s_inu[(r + tap / 3) * S + x + tap % 3];
+        const uint4 xr = {(xf.x >> 16) | (xf.x << 16), (xf.y >> 16) | (xf.y << 16), (xf.z >> 16) | (xf.z << 16),
+                          (xf.w >> 16) | (xf.w << 16)};
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8f_t, ws[ct][blk]), __builtin_bit_cast(f16x8f_t, xf), acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8f_t, ws[ct][blk]), __builtin_bit_cast(f16x8f_t, xr), acc[ct], 0, 0, 0);
+        }
+      }
+    } else {
+      float xb[9];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) xb[kh * 3 + kw] = s_inf[((r + kh) * S + x + kw) * 4 + lg];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][tap], xb[tap], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][tap], xb[tap], acc[1], 0, 0, 0);
+      }
     }
     if (px < npx) {
 #pragma unroll
@@ -1760,8 +1800,8 @@ extern "C" int vnf_mtcnn_create(const vnf_tensor_desc* pnet, int n_pnet, const v
         m->renc = new Encoder();
         m->renc->max_streams = 1;  // the detector shares the GPU with the embedding stream: no forks of its own
         m->renc->tune_batch = std::max(1, m->r_cap / 2);  // typical stage-2 load, not the capacity
-        // VNF_MTCNN_DTYPE=f32 keeps the R/O-Net plans on the exact-f32 MFMA; the default is split-f16 (two 16-bit MFMAs per
-        // product, ~22 significant bits) from conv2 on -- conv1 always runs in exact fp32 inside net_front_kernel
+        // VNF_MTCNN_DTYPE=f32 keeps the R/O-Net plans (and conv1 in net_front_kernel) on the exact-f32 MFMA; the default is
+        // split-f16 (two 16-bit MFMAs per product, ~22 significant bits) for every layer of both nets
         static const bool plans_f32 = getenv("VNF_MTCNN_DTYPE") && !strcmp(getenv("VNF_MTCNN_DTYPE"), "f32");
         m->renc->kind = 1; m->renc->arch = -2; m->renc->dtype = F32; m->renc->max_batch = m->r_cap;
         static const bool front_env = !getenv("VNF_MTCNN_FRONT") || atoi(getenv("VNF_MTCNN_FRONT")) != 0;
@@ -2050,7 +2090,12 @@ static int mtcnn_run(Mtcnn* m, const uint8_t* frames, int b, int H, int W, hipSt
         const size_t lr = (25 * 24 + 22 * 22 * 8) * 16, lo = (11 * 48 + 9 * 46 * 8) * 16;   // (IR * S + conv rows * C * 8) float4
         // R-Net: the whole candidate in one workgroup of 8 waves (no band overlap to recompute; measured 0.065 ms against
         // 0.074 for two bands x 4 waves); O-Net: bands of 4 pooled rows x 8 waves (larger bands / 16 waves were slower)
-        if (S == 24 && split) hipLaunchKernelGGL((net_front_kernel<24, 11, 512, true>), dim3(1, n), dim3(512), lr, s, cin, m->rfw, pout);
+        // conv1 of the split-f16 plans on the 16-bit MFMA as well (VNF_MTCNN_FRONT16=0: exact-fp32 conv1, three times the
+        // MFMA time); the f32 plans (VNF_MTCNN_DTYPE=f32) always take the exact kernel
+        static const bool mm16 = !getenv("VNF_MTCNN_FRONT16") || atoi(getenv("VNF_MTCNN_FRONT16")) != 0;
+        if (S == 24 && split && mm16) hipLaunchKernelGGL((net_front_kernel<24, 11, 512, true, true>), dim3(1, n), dim3(512), lr, s, cin, m->rfw, pout);
+        else if (S == 48 && split && mm16) hipLaunchKernelGGL((net_front_kernel<48, 4, 512, true, true>), dim3(6, n), dim3(512), lo, s, cin, m->ofw, pout);
+        else if (S == 24 && split) hipLaunchKernelGGL((net_front_kernel<24, 11, 512, true>), dim3(1, n), dim3(512), lr, s, cin, m->rfw, pout);
         else if (S == 24) hipLaunchKernelGGL((net_front_kernel<24, 11, 512, false>), dim3(1, n), dim3(512), lr, s, cin, m->rfw, pout);
         else if (split) hipLaunchKernelGGL((net_front_kernel<48, 4, 512, true>), dim3(6, n), dim3(512), lo, s, cin, m->ofw, pout);
         else hipLaunchKernelGGL((net_front_kernel<48, 4, 512, false>), dim3(6, n), dim3(512), lo, s, cin, m->ofw, pout);
