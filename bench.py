@@ -520,7 +520,9 @@ def main():
                     help="pipeline workload: faces of consecutive frame batches are embedded together once this many wait "
                          "(0: every frame batch on its own)")
     ap.add_argument("--detector", default="mtcnn", choices=["mtcnn", "retina"], help="detect / pipeline workloads: the detector plugin")
-    ap.add_argument("--detectors", type=int, default=1, help="pipeline workload: detector handles (host threads) per GPU")
+    ap.add_argument("--detectors", type=int, default=0,
+                    help="detector handles (host threads + streams) per GPU; default: 2 for the pipeline legs (the faster count since the "
+                         "round-3 cascade), 1 for the stream leg (its upload look-ahead is built around one submit thread) and detect")
     ap.add_argument("--lanes", type=int, default=0,
                     help="streams / encoder activation contexts that consecutive embed launches rotate over (1: one stream; the "
                          "embed workload's encoder then splits each batch over two internal streams instead); default 3 for the "
@@ -557,8 +559,11 @@ def main():
 
     def run_pipeline(dtype=None, from_host=False, cpu=True):
         st = args.steps if args.workload in ("pipeline", "stream") else max(10, args.steps // 2)
+        import copy
+        a = copy.copy(args)
+        a.detectors = args.detectors if args.detectors > 0 else (1 if from_host else 2)
         try:
-            return pipeline_leg(args, rank, world, local, st, args.warmup, pipe_lanes, want_cpu and cpu, dtype=dtype, from_host=from_host)
+            return pipeline_leg(a, rank, world, local, st, args.warmup, pipe_lanes, want_cpu and cpu, dtype=dtype, from_host=from_host)
         except Exception as e:
             if args.workload in ("pipeline", "stream"):
                 raise
