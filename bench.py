@@ -558,7 +558,7 @@ def main():
     pipe_first = os.environ.get("BENCH_PIPE_FIRST", "0") != "0"
 
     def run_pipeline(dtype=None, from_host=False, cpu=True):
-        st = args.steps if args.workload in ("pipeline", "stream") else max(10, args.steps // 2)
+        st = args.steps   # every pipeline leg times the full K steps: with 50 the fill / drain of the two-handle pipeline showed (87 k against 95 k)
         import copy
         a = copy.copy(args)
         a.detectors = args.detectors if args.detectors > 0 else (1 if from_host else 2)
@@ -575,6 +575,10 @@ def main():
         p = run_pipeline()
     if args.workload in ("all", "embed"):
         out = embed_leg(args, args.dtype, rank, world, dev, emb_lanes, args.steps, args.warmup, want_cpu)
+    # the pipeline leg runs right behind the headline leg: after the minute of side legs below the chip holds a lower
+    # clock (MI355X_MICROARCH.md, DVFS) and the same leg reads 8-9 % lower (87 k against 95 k faces/s)
+    if args.workload == "all" and not pipe_first:
+        p = run_pipeline()
     if args.workload == "all" and args.model == "irv1":
         # the other compute dtypes: shorter legs (the f32 leg runs ~7 ms steps), no CPU baseline; then the headline dtype
         # on ONE lane (no overlap of independent batches) and BASELINE configs[4] (IR-100 swap-in encoder)
@@ -598,7 +602,7 @@ def main():
             if ig and "error" not in ig:
                 out["in_gate"] = {"dtype": "f16x2", "value": ig["value"], "unit": ig["unit"],
                                   "within_gate": bool(ig.get("parity", {}).get("within_gate")), "frac": ig["roofline"]["frac"]}
-    if args.workload in ("all", "pipeline") and not pipe_first:
+    if args.workload == "pipeline" and not pipe_first:
         p = run_pipeline()
     if args.workload == "stream":
         p = run_pipeline(dtype=args.dtype, from_host=True)
