@@ -40,6 +40,7 @@ python bench.py --workload embed --model ir100 --no-cpu-baseline > $OUT/${R}_ben
 python tools/run_layers.py bf16 2>/dev/null | grep -av amdgpu.ids > $OUT/${R}_irv1_bs256_bf16_layer_times.txt || exit 1   # one lane, no internal half-batch forks
 python tools/run_layers.py f16x2 2>/dev/null | grep -av amdgpu.ids > $OUT/${R}_irv1_bs256_f16x2_layer_times.txt || exit 1
 python bench.py --workload stream --dtype f16x2 --no-cpu-baseline > $OUT/${R}_bench_stream_f16x2.json 2>/dev/null || exit 1
+python bench.py --workload stream --no-cpu-baseline > $OUT/${R}_bench_stream_bf16.json 2>/dev/null || exit 1   # bf16: compute no longer hides the PCIe ceiling
 python bench.py --workload pipeline --detectors 1 --no-cpu-baseline > $OUT/${R}_bench_pipeline_1handle.json 2>/dev/null || exit 1   # the default line uses two handles
 # 3b. detector stage / layer tables (MTCNN cascade on 16 x 1080p; RetinaFace swap-in detector)
 python tools/mtcnn_layers.py > $OUT/${R}_mtcnn_stage_times.txt 2>&1 || exit 1
