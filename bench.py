@@ -561,7 +561,9 @@ def main():
         st = args.steps   # every pipeline leg times the full K steps: with 50 the fill / drain of the two-handle pipeline showed (87 k against 95 k)
         import copy
         a = copy.copy(args)
-        a.detectors = args.detectors if args.detectors > 0 else (1 if from_host else 2)
+        # two handles (host threads) only in the single-process run: the multi-rank line keeps the one-handle pipeline
+        # that the collective exchange was written and tested around
+        a.detectors = args.detectors if args.detectors > 0 else (1 if (from_host or world > 1) else 2)
         try:
             return pipeline_leg(a, rank, world, local, st, args.warmup, pipe_lanes, want_cpu and cpu, dtype=dtype, from_host=from_host)
         except Exception as e:
